@@ -1,0 +1,138 @@
+"""The CPU oracle (oracle/) against the golden vectors captured from the reference."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import decode as orc
+from oracle import forward as ofw
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_munkres_matches_pinned_library():
+    d = np.load(os.path.join(GOLDEN, "munkres.npz"))
+    n = len([k for k in d.files if k.startswith("m")])
+    assert n == 60
+    for i in range(n):
+        assert np.array_equal(orc.munkres(d[f"m{i}"]), d[f"r{i}"]), f"case {i} {d[f'm{i}'].shape}"
+
+
+def test_multi_scale_size_table():
+    rows = json.load(open(os.path.join(GOLDEN, "multi_scale_size.json")))
+    for r in rows:
+        size, center, scale = orc.get_multi_scale_size(r["h"], r["w"], r["input_size"], r["current_scale"], r["min_scale"])
+        assert list(size) == r["size"] and list(center) == r["center"]
+        assert [float(scale[0]), float(scale[1])] == r["scale"]
+
+
+def test_transform_coords_closed_form():
+    # hand-solved: 640x480 image -> 704x512 input (scale_w = 704/512*480 = 660): centre maps to centre,
+    # one model-input pixel is scale_w/dst_w = 0.9375 raw pixels on both axes.
+    out = orc.transform_coords(np.array([[352.0, 256.0], [353.0, 258.0], [0.0, 0.0]], np.float32), (320, 240), (660.0, 480.0), (704, 512))
+    assert np.allclose(out, [[320, 240], [320.9375, 241.875], [320 - 352 * 0.9375, 240 - 256 * 0.9375]], atol=1e-12)
+
+
+def test_bilinear_bit_exact_vs_torch_cpu():
+    torch.manual_seed(0)
+    for c, h, w, H, W in [(17, 64, 64, 128, 128), (17, 32, 48, 128, 192), (3, 40, 40, 160, 160), (5, 17, 23, 100, 77)]:
+        x = torch.randn(1, c, h, w)
+        y = torch.nn.functional.interpolate(x, size=[H, W], mode="bilinear", align_corners=False)[0].numpy()
+        assert np.array_equal(orc.bilinear(x[0].numpy(), H, W), y)
+
+
+def _case_inputs(synth, m):
+    return synth.synth_decode_maps(17, m["hq"], m["wq"], m["people"], seed=m["seed"], emb=m["emb"], **m["kwargs"])
+
+
+def test_decode_cases_bit_exact(synth, decode_golden):
+    meta, g = decode_golden
+    assert len(meta) >= 14
+    for tag, m in meta.items():
+        hm_q, hm_h, tags, _ = _case_inputs(synth, m)
+        full, tfull = orc.aggregate(hm_q, hm_h, tags)
+        assert _sha(full) == m["full_hm_sha256"], tag
+        assert _sha(tfull) == m["full_tags_sha256"], tag
+        tk, ck, sk = orc.top_k(full, tfull, m["max_people"])
+        gs, gc, gt = g[tag + "/scores_k"], g[tag + "/coords_k"], g[tag + "/tags_k"]
+        if m["has_ties"]:
+            # torch.topk leaves the order of equal values unspecified: compare as sets per joint
+            for k in range(17):
+                pos = gs[k] > 0
+                a = sorted(zip(gs[k][pos].tolist(), map(tuple, gc[k][pos].tolist())))
+                b = sorted(zip(sk[k][sk[k] > 0].tolist(), map(tuple, ck[k][sk[k] > 0].tolist())))
+                assert a == b, (tag, k)
+        else:
+            pos = gs > 0
+            assert np.array_equal(sk[pos], gs[pos]) and np.array_equal(ck[pos], gc[pos]) and np.array_equal(tk[pos], gt[pos]), tag
+        # grouping on the reference's own candidates: always bit exact
+        gr = orc.match_by_tag(gt, gc, gs, m["det_thr"], m["tag_thr"])
+        ref = g[tag + "/grouped"]
+        assert gr.shape[0] == ref.shape[0] and (ref.size == 0 or np.array_equal(gr, ref)), tag
+        if ref.size:
+            assert np.array_equal(orc.adjust(ref, full), g[tag + "/adjusted"]), tag
+        if m["has_ties"]:
+            continue
+        for name, (a, r) in {"joints": (1, 1), "joints_norefine": (1, 0), "joints_noadjust": (0, 1)}.items():
+            j, s = orc.parse(full, tfull, max_people=m["max_people"], det_thr=m["det_thr"], tag_thr=m["tag_thr"], adjust=a, refine=r)
+            ref = g[tag + "/" + name].astype(np.float32)
+            assert j.shape == ref.shape and np.array_equal(j, ref), (tag, name)
+            if name == "joints":
+                assert np.array_equal(s, g[tag + "/scores"].astype(np.float32)), tag
+
+
+def _synth_sd(synth, pkg, C, seed):
+    from torch import nn
+    import importlib
+    spec = importlib.import_module(pkg.__name__ + ".keypoints.architectures.spec")
+    root = nn.Module()
+    spec.attach_modules(root, spec.higher_hrnet_rows(17, C))
+    return {k: torch.from_numpy(synth.synth_param(k, v.shape, seed)) for k, v in root.state_dict().items()}
+
+
+@pytest.mark.parametrize("tag,C,B,H,W,seed", [("w32_64", 32, 1, 64, 64, 0), ("w32_128", 32, 2, 128, 128, 1),
+                                              ("w32_96x160", 32, 1, 96, 160, 2), ("w48_64", 48, 1, 64, 64, 3)])
+def test_forward_oracle_vs_reference_outputs(pkg, synth, net_golden, tag, C, B, H, W, seed):
+    sd = _synth_sd(synth, pkg, C, seed)
+    assert len(sd) == 1810
+    x = torch.from_numpy(synth.synth_images(B, H, W, seed))
+    with torch.no_grad():
+        hms, tags, taps = ofw.higher_hrnet(x, sd, 17, return_taps=True)
+    # same ATen ops in the same order -> identical up to thread-partitioning noise
+    for name, t in (("hm_q", hms[0]), ("hm_h", hms[1]), ("tags", tags)):
+        ref = net_golden[f"{tag}/{name}"]
+        assert t.shape == ref.shape
+        assert np.allclose(t.numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max()), (tag, name)
+    for k in net_golden.files:
+        if k.startswith(f"{tag}/tap/"):
+            name = k.split("/tap/")[1]
+            ref = net_golden[k]
+            assert np.allclose(taps[name].numpy(), ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max())), name
+
+
+def test_forward_oracle_full_size_samples(pkg, synth, net_golden):
+    sd = _synth_sd(synth, pkg, 32, 0)
+    x = torch.from_numpy(synth.synth_images(1, 512, 512, 7))
+    with torch.no_grad():
+        hms, tags = ofw.higher_hrnet(x, sd, 17)
+    for name, t in (("hm_q", hms[0]), ("hm_h", hms[1]), ("tags", tags)):
+        idx = net_golden[f"w32_512/{name}_idx"]
+        ref = net_golden[f"w32_512/{name}_val"]
+        got = t.numpy().reshape(-1)[idx]
+        assert np.allclose(got, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max()), name
+
+
+def test_flip_tta_oracle(pkg, synth):
+    g = np.load(os.path.join(GOLDEN, "flip_tta.npz"))
+    sd = _synth_sd(synth, pkg, 32, 0)
+    x = torch.from_numpy(synth.synth_images(1, 64, 64, 21))
+    with torch.no_grad():
+        hms, tags = ofw.flip_tta(x, sd, 17)
+    for name, t in (("hm_q", hms[0]), ("hm_h", hms[1]), ("tags0", tags[0]), ("tags1", tags[1])):
+        assert np.allclose(t.numpy(), g[name], rtol=1e-4, atol=1e-4 * np.abs(g[name]).max()), name

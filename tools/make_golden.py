@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference and the pinned munkres 1.1.4 that
+ships in the container's conda tree); nothing here travels to the GPU box except the .npz /
+.json files it writes.  Recipe from SURVEY.md §8c:
+
+  PYTHONDONTWRITEBYTECODE=1 python3 tools/make_golden.py
+
+What is imported from the reference (and therefore *pinned* by these fixtures):
+  * src.keypoints.architectures.higher_hrnet.HigherHRNet         (net forward, a1-a9)
+  * src.classification.architectures.hrnet.ClassificationHRNet   (cfg 1, a22)
+  * src.keypoints.grouping.MPPEHeatmapParser                     (decode, a12-a17)
+  * munkres.Munkres 1.1.4                                        (assignment, a14)
+  * src.base.transforms.utils.get_multi_scale_size               (resize geometry, a10)
+What is NOT importable here (cv2 / torchvision missing) and is restated inline with the
+same torch calls the reference makes: the three F.interpolate(bilinear,
+align_corners=False) + stack/mean lines of results.py:48-67,225-230 and the flip-TTA
+lines of model.py:85-94.
+
+Inputs and weights are produced by this repo's own seeded generators (synth.py), so the
+fixtures hold outputs only.
+"""
+import hashlib
+import importlib
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+MUNKRES = "/opt/conda/lib/python3.9/site-packages/munkres.py"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+spec = importlib.util.spec_from_file_location("munkres", MUNKRES)
+munkres = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(munkres)
+assert munkres.__version__ == "1.1.4"
+sys.modules["munkres"] = munkres
+
+synth = importlib.import_module("pytorch-human-pose_amd.synth")
+from src.classification.architectures.hrnet import ClassificationHRNet  # noqa: E402
+from src.keypoints.architectures.higher_hrnet import HigherHRNet  # noqa: E402
+from src.keypoints.grouping import MPPEHeatmapParser  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+COCO_FLIP_INDEX = [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15]  # transforms.py:11
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load_synth(net: torch.nn.Module, seed: int) -> None:
+    sd = net.state_dict()
+    new = {k: torch.from_numpy(synth.synth_param(k, v.shape, seed)) for k, v in sd.items()}
+    net.load_state_dict(new, strict=True)
+    net.eval()
+
+
+# ------------------------------------------------------------------ net forward fixtures
+def net_fixtures():
+    out = {}
+    # (tag, C, B, H, W, seed, taps?)
+    cases = [("w32_64", 32, 1, 64, 64, 0, True), ("w32_128", 32, 2, 128, 128, 1, False),
+             ("w32_96x160", 32, 1, 96, 160, 2, False), ("w48_64", 48, 1, 64, 64, 3, False)]
+    for tag, C, B, H, W, seed, taps in cases:
+        net = HigherHRNet(17, C)
+        load_synth(net, seed)
+        x = torch.from_numpy(synth.synth_images(B, H, W, seed))
+        captured = {}
+        hooks = []
+        if taps:
+            def mk(name):
+                def hook(_m, _inp, outp):
+                    ts = outp if isinstance(outp, (list, tuple)) else [outp]
+                    for i, t in enumerate(ts):
+                        captured[f"{name}#{i}"] = t.detach().clone().numpy()
+                return hook
+            hooks.append(net.backbone.stages[0].register_forward_pre_hook(
+                lambda _m, inp: captured.__setitem__("stem#0", inp[0].detach().clone().numpy())))
+            for s, st in enumerate(net.backbone.stages):
+                for b, blk in enumerate(st.blocks):
+                    hooks.append(blk.register_forward_hook(mk(f"stages.{s}.blocks.{b}")))
+                hooks.append(st.register_forward_hook(mk(f"stages.{s}")))
+            hooks.append(net.deconv_layers[0].register_forward_hook(mk("deconv")))
+        with torch.no_grad():
+            hms, tags = net(x)
+        for h in hooks:
+            h.remove()
+        out[f"{tag}/hm_q"] = hms[0].numpy()
+        out[f"{tag}/hm_h"] = hms[1].numpy()
+        out[f"{tag}/tags"] = tags.numpy()
+        for k, v in captured.items():
+            out[f"{tag}/tap/{k}"] = v
+        print(tag, [tuple(h.shape) for h in hms], float(hms[0].abs().max()), float(hms[1].abs().max()),
+              float(tags.abs().max()), len(captured))
+    # full-size W32 512x512: sampled positions + checksums only
+    net = HigherHRNet(17, 32)
+    load_synth(net, 0)
+    x = torch.from_numpy(synth.synth_images(1, 512, 512, 7))
+    with torch.no_grad():
+        hms, tags = net(x)
+    rs = np.random.RandomState(5)
+    for name, t in (("hm_q", hms[0]), ("hm_h", hms[1]), ("tags", tags)):
+        a = t.numpy()
+        idx = rs.randint(0, a.size, 4096)
+        out[f"w32_512/{name}_idx"] = idx.astype(np.int64)
+        out[f"w32_512/{name}_val"] = a.reshape(-1)[idx]
+        out[f"w32_512/{name}_stats"] = np.array([a.mean(), a.std(), np.abs(a).max()], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "net_forward.npz"), **out)
+
+    # cfg 1: ClassificationHRNet-W32 on one 224x224 image
+    cnet = ClassificationHRNet(32, 1000)
+    load_synth(cnet, 11)
+    x = torch.from_numpy(synth.synth_images(1, 224, 224, 11))
+    with torch.no_grad():
+        logits = cnet(x)
+    np.savez_compressed(os.path.join(OUT, "cls_forward.npz"), logits=logits.numpy())
+    print("cls logits", float(logits.abs().max()))
+
+
+# ------------------------------------------------------------------ decode fixtures
+def aggregate(hm_q, hm_h, tags_list):
+    """results.py:225-234 restated with the same torch calls (module not importable: cv2)."""
+    hq = torch.from_numpy(hm_q)[None]
+    hh = torch.from_numpy(hm_h)[None]
+    H, W = hh.shape[-2] * 2, hh.shape[-1] * 2
+    interp = torch.nn.functional.interpolate
+    up = interp(hq, size=list(hh.shape[-2:]), mode="bilinear", align_corners=False)
+    avg = torch.stack([up, hh]).mean(dim=0)
+    full = interp(avg, size=[H, W], mode="bilinear", align_corners=False)
+    tfull = [interp(torch.from_numpy(t)[None], size=[H, W], mode="bilinear", align_corners=False) for t in tags_list]
+    tfull = torch.stack(tfull, dim=4)
+    return full[0], tfull[0]
+
+
+DECODE_CASES = [
+    # tag, hq, wq, people, seed, emb, det_thr, tag_thr, max_people, kwargs
+    # NB: torch's CPU bilinear switches to a differently-rounded vectorised kernel when
+    # out_h + out_w <= 128 (ATen UpSampleKernel.cpp, _use_vectorized_kernel_cond_2d); real inputs
+    # (>= 256 px) never reach it, so every case keeps 2*hq + 2*wq > 128.
+    ("p3_160", 40, 40, 3, 1, 1, 0.05, 0.5, 30, {}),
+    ("p3_160_e2", 40, 40, 3, 2, 2, 0.05, 0.5, 30, {}),
+    ("p0_160", 40, 40, 0, 3, 1, 0.05, 0.5, 30, {}),
+    ("p1_160", 40, 40, 1, 4, 1, 0.05, 0.5, 30, {}),
+    ("p5_ragged", 32, 48, 5, 5, 1, 0.05, 0.5, 30, {}),
+    ("p5_ragged_b", 56, 40, 5, 15, 1, 0.05, 0.5, 30, {}),
+    ("p6_missing", 48, 48, 6, 6, 1, 0.05, 0.5, 30, {"drop_prob": 0.5}),
+    ("p4_zero_bg", 40, 40, 4, 7, 1, 0.05, 0.5, 30, {"bg": 0.0}),
+    ("p8_val_thr", 48, 48, 8, 8, 1, 0.1, 1.0, 20, {}),
+    ("p10_512", 128, 128, 10, 9, 1, 0.05, 0.5, 30, {}),
+    ("p10_512_e2", 128, 128, 10, 10, 2, 0.05, 0.5, 30, {}),
+    ("p35_512", 128, 128, 35, 11, 1, 0.05, 0.5, 30, {"sigma": 1.5}),
+    ("p12_close_tags", 64, 64, 12, 12, 1, 0.05, 0.5, 30, {"tag_spacing": 0.4, "tag_noise": 0.15}),
+    ("p40_cap5", 64, 64, 40, 13, 1, 0.05, 0.5, 5, {"sigma": 1.5}),
+]
+
+
+def decode_fixtures():
+    out = {}
+    meta = {}
+    for tag, hq, wq, P, seed, emb, det, tthr, maxp, kw in DECODE_CASES:
+        hm_q, hm_h, tags, _ = synth.synth_decode_maps(17, hq, wq, P, seed=seed, emb=emb, **kw)
+        full, tfull = aggregate(hm_q, hm_h, tags)
+        parser = MPPEHeatmapParser(17, max_num_people=maxp, det_thr=det, tag_thr=tthr)
+        tags_k, coords_k, scores_k = parser.top_k(full, tfull)
+        grouped = parser.match_by_tag(tags_k, coords_k, scores_k)
+        if len(grouped):
+            adjusted = parser.adjust(grouped.copy(), full.numpy())
+        else:
+            adjusted = grouped
+        joints, scores = parser.parse(full, tfull, adjust=True, refine=True)
+        joints_nr, scores_nr = parser.parse(full, tfull, adjust=True, refine=False)
+        joints_na, _ = parser.parse(full, tfull, adjust=False, refine=True)
+        out[f"{tag}/tags_k"] = tags_k
+        out[f"{tag}/coords_k"] = coords_k
+        out[f"{tag}/scores_k"] = scores_k
+        out[f"{tag}/grouped"] = grouped
+        out[f"{tag}/adjusted"] = adjusted
+        out[f"{tag}/joints"] = joints
+        out[f"{tag}/scores"] = scores
+        out[f"{tag}/joints_norefine"] = joints_nr
+        out[f"{tag}/joints_noadjust"] = joints_na
+        meta[tag] = dict(hq=hq, wq=wq, people=P, seed=seed, emb=emb, det_thr=det, tag_thr=tthr, max_people=maxp,
+                         kwargs=kw, full_hm_sha256=sha(full.numpy()), full_tags_sha256=sha(tfull.numpy()),
+                         num_found=int(len(joints)),
+                         # exact ties among candidates: torch.topk's order between equal values is
+                         # unspecified (CPU heap sort vs CUDA radix select), tests compare those as sets
+                         has_ties=bool(any(len(np.unique(r[r > 0])) != int((r > 0).sum()) for r in scores_k)))
+        print(tag, "found", len(joints), "of", P, "topk min score", float(scores_k.min()), "ties", meta[tag]["has_ties"])
+    np.savez_compressed(os.path.join(OUT, "decode.npz"), **out)
+    with open(os.path.join(OUT, "decode_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+# ------------------------------------------------------------------ flip TTA fixture
+def flip_fixture():
+    """model.py:85-94 restated (module not importable: torchvision). Net is the reference's."""
+    net = HigherHRNet(17, 32)
+    load_synth(net, 0)
+    x = torch.from_numpy(synth.synth_images(1, 64, 64, 21))
+    with torch.no_grad():
+        hms, tags = net(x)
+        fh, ft = net(torch.flip(x, [3]))
+        hms = [(hms[i] + torch.flip(fh[i], [3])[:, COCO_FLIP_INDEX]) / 2 for i in range(2)]
+        tags2 = torch.flip(ft, [3])[:, COCO_FLIP_INDEX]
+    np.savez_compressed(os.path.join(OUT, "flip_tta.npz"), hm_q=hms[0].numpy(), hm_h=hms[1].numpy(),
+                        tags0=tags.numpy(), tags1=tags2.numpy())
+
+
+# ------------------------------------------------------------------ munkres fixtures
+def munkres_fixtures():
+    rs = np.random.RandomState(77)
+    mats, res = {}, {}
+    for i in range(60):
+        r = int(rs.randint(1, 31))
+        c = int(rs.randint(1, 31))
+        kind = i % 4
+        if kind == 0:
+            m = rs.uniform(0, 10, (r, c))
+        elif kind == 1:  # the reference's cost shape: round(dist)*100 - score, many ties
+            m = np.round(rs.uniform(0, 3, (r, c))) * 100 - rs.uniform(0.05, 1.0, (r, 1)).astype(np.float32).astype(np.float64)
+        elif kind == 2:  # with the 1e10 padding columns of grouping.py:126-128
+            m = np.round(rs.uniform(0, 2, (r, c))) * 100 - rs.uniform(0.05, 1.0, (r, 1))
+            if r > c:
+                m = np.concatenate([m, np.zeros((r, r - c)) + 1e10], axis=1)
+        else:  # small integers, heavy ties
+            m = rs.randint(0, 4, (r, c)).astype(np.float64)
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        # numpy input as grouping.py:55-59 passes it (needs cols >= rows: munkres' pad_matrix cannot
+        # extend numpy rows); otherwise plain lists, the library's documented input type.
+        pairs = munkres.Munkres().compute(m.copy() if m.shape[1] >= m.shape[0] else m.tolist())
+        mats[f"m{i}"] = m
+        res[f"r{i}"] = np.array(pairs, dtype=np.int32).reshape(-1, 2)
+    np.savez_compressed(os.path.join(OUT, "munkres.npz"), **mats, **res)
+    print("munkres cases", len(mats))
+
+
+# ------------------------------------------------------------------ resize geometry
+def geometry_fixtures():
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))  # utils.py:2 imports cv2; the function below never touches it
+    from src.base.transforms.utils import get_multi_scale_size
+    rows = []
+    for (h, w) in [(480, 640), (640, 480), (427, 640), (512, 512), (333, 500), (1080, 1920), (375, 500)]:
+        for input_size in (512, 640):
+            for cur, mn in [(1, 1), (0.5, 0.5), (1, 0.5), (2, 0.5)]:
+                size, center, scale = get_multi_scale_size(np.zeros((h, w, 3), np.uint8), input_size, cur, mn)
+                rows.append(dict(h=h, w=w, input_size=input_size, current_scale=cur, min_scale=mn,
+                                 size=[int(size[0]), int(size[1])], center=[int(center[0]), int(center[1])],
+                                 scale=[float(scale[0]), float(scale[1])]))
+    with open(os.path.join(OUT, "multi_scale_size.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+    print("geometry rows", len(rows))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["net", "decode", "flip", "munkres", "geometry"]
+    if "munkres" in which:
+        munkres_fixtures()
+    if "geometry" in which:
+        geometry_fixtures()
+    if "decode" in which:
+        decode_fixtures()
+    if "flip" in which:
+        flip_fixture()
+    if "net" in which:
+        net_fixtures()
