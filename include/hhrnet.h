@@ -1,0 +1,125 @@
+/*
+ * hhrnet.h -- C-ABI of the MI355X-native HigherHRNet forward + associative-embedding decode.
+ *
+ * The reference (thawro/pytorch-human-pose) has no FFI: its plug-in points are Python
+ * classes.  Each entry point below names the reference interface it stands in for
+ * (paths relative to the reference's src/); the Python shims in
+ * pytorch-human-pose_amd/keypoints/ bind them with ctypes.
+ *
+ * Conventions: every function returning int returns 0 on success, non-zero on error with
+ * a thread-local message in hh_last_error().  All *device* pointers are plain HIP device
+ * addresses (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void*
+ * (NULL = the legacy default stream).  Calls are asynchronous on `stream` unless noted.
+ * A handle is not re-entrant; different handles may be used from different threads.
+ */
+#ifndef HHRNET_H
+#define HHRNET_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HH_ABI_VERSION 1
+#define HH_DTYPE_BF16 1 /* bf16 MFMA operands, fp32 accumulate, bf16 NHWC activations */
+
+typedef struct hh_net hh_net;
+typedef struct hh_decoder hh_decoder;
+
+int hh_abi_version(void);
+const char *hh_last_error(void);
+
+/* ------------------------------------------------------------------ network forward
+ * hh_create: HigherHRNet(num_kpts, C).__init__ -- keypoints/architectures/higher_hrnet.py:47-64
+ * (backbone: hrnet.py:342-376).  Parameters are addressed by the reference's state-dict
+ * key names (1810 keys for W32).                                                        */
+hh_net *hh_create(int num_kpts, int C, int dtype);
+void hh_destroy(hh_net *net);
+
+/* state_dict() introspection: key names and shapes in the reference's order. */
+int hh_num_params(const hh_net *net);
+const char *hh_param_name(const hh_net *net, int index);
+int hh_param_shape(const hh_net *net, int index, int64_t shape[4]); /* returns ndim (0 for scalars) */
+
+/* load_state_dict(): base/model.py:155-175. `host` is fp32 (int64 counters are ignored);
+ * unknown names and shape mismatches are errors (strict=True semantics).                */
+int hh_load_weights(hh_net *net, const char *name, const float *host, const int64_t *shape, int ndim);
+/* Folds eval-mode BatchNorm (eps 1e-5) into the preceding conv, packs bf16 kernel-layout
+ * weights and uploads them.  Fails if any parameter was never loaded.  Synchronous.     */
+int hh_finalize(hh_net *net);
+
+/* Allocates the activation workspace for inputs up to [B,3,H,W] (H, W multiples of 32).
+ * Synchronous; hh_forward calls it implicitly when the shape grows.                     */
+int hh_reserve(hh_net *net, int B, int H, int W);
+int64_t hh_workspace_bytes(const hh_net *net);
+
+/* HigherHRNet.forward: higher_hrnet.py:66-81.
+ *   images          [B,3,H,W]        fp32 NCHW (device)
+ *   init_heatmaps   [B,2K,H/4,W/4]   fp32 NCHW (device): stage-0 heatmaps = [:, :K], tags = [:, K:]
+ *   deconv_heatmaps [B,K,H/2,W/2]    fp32 NCHW (device): stage-1 heatmaps
+ * use_graph != 0 replays a cached hipGraph when (pointers, shape) repeat.               */
+int hh_forward(hh_net *net, const float *images, int B, int H, int W, float *init_heatmaps, float *deconv_heatmaps,
+               int use_graph, void *stream);
+
+/* Algorithmic conv/deconv FLOPs (2*MACs) of one forward at this shape -- SURVEY.md §8d.  */
+double hh_forward_flops(const hh_net *net, int B, int H, int W);
+
+/* Debug taps (parity tests): when enabled, hh_forward copies selected intermediate
+ * activations; hh_tap_read converts one to fp32 NCHW on the host. Names follow the
+ * reference module paths, e.g. "stages.2.blocks.3#1" = output 1 of backbone.stages[2].blocks[3]. */
+int hh_set_taps(hh_net *net, int enable);
+int hh_num_taps(const hh_net *net);
+const char *hh_tap_name(const hh_net *net, int index);
+int hh_tap_shape(const hh_net *net, int index, int64_t shape[4]); /* N,C,H,W of the last forward */
+int hh_tap_read(hh_net *net, int index, float *host_nchw);        /* synchronous */
+
+/* Flip test-time augmentation, keypoints/model.py:85-94 (COCO_FLIP_INDEX: keypoints/transforms.py:11).
+ * hh_flip_images: out = flip(images, W axis), fp32 NCHW.
+ * hh_flip_merge : hm[b,k] = (hm[b,k] + flip_w(hm_flipped[b, perm[k]])) / 2  in place for `hm`
+ *                 (K channels each, batch strides in elements), and
+ *                 tags_out[b,k] = flip_w(tags_flipped[b, perm[k]]).                       */
+int hh_flip_images(const float *images, float *out, int B, int C, int H, int W, void *stream);
+int hh_flip_merge(float *hm, int64_t hm_bstride, const float *hm_flipped, int64_t hmf_bstride, const float *tags_flipped,
+                  int64_t tf_bstride, float *tags_out, int64_t to_bstride, const int32_t *perm_host, int B, int K,
+                  int h, int w, void *stream);
+
+/* ------------------------------------------------------------------ decode
+ * hh_decoder_create: MPPEHeatmapParser(num_kpts, max_num_people, det_thr, tag_thr)
+ * -- keypoints/grouping.py:67-78.  Thresholds are doubles because the reference compares
+ * float32 scores / float64 distances against Python floats.                             */
+hh_decoder *hh_decoder_create(int num_kpts, int max_people, double det_thr, double tag_thr);
+void hh_decoder_destroy(hh_decoder *dec);
+int hh_decoder_reserve(hh_decoder *dec, int B, int H, int W, int E); /* H, W = full (model-input) resolution */
+
+/* InferenceKeypointsResult.from_preds aggregation + MPPEHeatmapParser.parse, batched:
+ * keypoints/results.py:225-238 + keypoints/grouping.py:252-283.
+ *   hm_q   [B,K,hq,wq]   fp32, batch stride hm_q_bstride elements (channel-slice views allowed)
+ *   hm_h   [B,K,2hq,2wq] fp32
+ *   tags_q E pointers (host array of device pointers), each [B,K,hq,wq]
+ * Outputs (device): joints [B,max_people,K,3+E] (x, y, score, tag...; zero rows = no person),
+ * scores [B,max_people], num_people [B].  Bit-exact with the reference on identical inputs
+ * (ties between equal candidate scores are ordered by ascending pixel index).           */
+int hh_decode(hh_decoder *dec, const float *hm_q, int64_t hm_q_bstride, const float *hm_h, int64_t hm_h_bstride,
+              const float *const *tags_q, const int64_t *tags_bstride, int E, int B, int hq, int wq, int adjust,
+              int refine, float *joints, float *scores, int32_t *num_people, void *stream);
+
+/* MPPEHeatmapParser.parse on explicit full-resolution maps (grouping.py:252-283):
+ *   hm_full [B,K,H,W] fp32, tags_full [B,K,H,W,E] fp32 (both contiguous).              */
+int hh_parse(hh_decoder *dec, const float *hm_full, const float *tags_full, int E, int B, int H, int W, int adjust,
+             int refine, float *joints, float *scores, int32_t *num_people, void *stream);
+
+/* Candidates of the last hh_decode/hh_parse call (MPPEHeatmapParser.top_k, grouping.py:147-170),
+ * copied to host: tags_k [B,K,max_people,E], coords_k [B,K,max_people,2] (x,y), scores_k [B,K,max_people].
+ * Synchronous; for parity tests.                                                        */
+int hh_decoder_read_topk(hh_decoder *dec, float *tags_k, int32_t *coords_k, float *scores_k);
+
+/* get_final_kpts_coords / transform_coords: keypoints/results.py:158-171,189-201 with
+ * get_affine_transform(inverse=True, rot=0) (base/transforms/utils.py:25-57). Host-side,
+ * float64: xy_out[i] = (xy_in[i] - dst/2) * scale_w/dst_w + center.                      */
+int hh_transform_coords(const float *xy_in, int n, double center_x, double center_y, double scale_w, double dst_w,
+                        double dst_h, double *xy_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HHRNET_H */

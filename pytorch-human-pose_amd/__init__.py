@@ -1,0 +1,6 @@
+"""MI355X-native HigherHRNet forward + associative-embedding decode (drop-in for the
+`src.keypoints` model/inference API of thawro/pytorch-human-pose).  See DESIGN.md."""
+from . import _lib, synth
+from .keypoints import HigherHRNet, InferenceKeypointsModel, InferenceKeypointsResult, MPPEHeatmapParser
+
+__all__ = ["HigherHRNet", "MPPEHeatmapParser", "InferenceKeypointsModel", "InferenceKeypointsResult", "synth", "_lib"]

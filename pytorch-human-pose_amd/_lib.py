@@ -1,0 +1,95 @@
+"""ctypes binding of csrc/libhhrnet.so (the C-ABI declared in include/hhrnet.h).
+
+There is no CPU fallback: if the HIP library cannot be loaded every product entry point
+raises.  `build()` compiles it in-tree with hipcc for gfx950 (works without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO = os.path.join(CSRC, "libhhrnet.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "hhrnet.h")
+_lib = None
+
+
+class HHError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, jobs: int = 8) -> str:
+    args = ["make", "-C", CSRC, f"-j{jobs}"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return SO
+
+
+def _sig(lib):
+    i32, i64, dbl, vp, cp = C.c_int, C.c_int64, C.c_double, C.c_void_p, C.c_char_p
+    pi64 = C.POINTER(C.c_int64)
+    sigs = {
+        "hh_abi_version": (i32, []),
+        "hh_last_error": (cp, []),
+        "hh_create": (vp, [i32, i32, i32]),
+        "hh_destroy": (None, [vp]),
+        "hh_num_params": (i32, [vp]),
+        "hh_param_name": (cp, [vp, i32]),
+        "hh_param_shape": (i32, [vp, i32, pi64]),
+        "hh_load_weights": (i32, [vp, cp, vp, pi64, i32]),
+        "hh_finalize": (i32, [vp]),
+        "hh_reserve": (i32, [vp, i32, i32, i32]),
+        "hh_workspace_bytes": (i64, [vp]),
+        "hh_forward": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, vp]),
+        "hh_forward_flops": (dbl, [vp, i32, i32, i32]),
+        "hh_set_taps": (i32, [vp, i32]),
+        "hh_num_taps": (i32, [vp]),
+        "hh_tap_name": (cp, [vp, i32]),
+        "hh_tap_shape": (i32, [vp, i32, pi64]),
+        "hh_tap_read": (i32, [vp, i32, vp]),
+        "hh_flip_images": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+        "hh_flip_merge": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
+        "hh_decoder_create": (vp, [i32, i32, dbl, dbl]),
+        "hh_decoder_destroy": (None, [vp]),
+        "hh_decoder_reserve": (i32, [vp, i32, i32, i32, i32]),
+        "hh_decode": (i32, [vp, vp, i64, vp, i64, vp, pi64, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+        "hh_parse": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+        "hh_decoder_read_topk": (i32, [vp, vp, vp, vp]),
+        "hh_transform_coords": (i32, [vp, i32, dbl, dbl, dbl, dbl, dbl, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sigs
+
+
+def exported_symbols() -> list[str]:
+    """Entry points declared in include/hhrnet.h (parsed from the header text)."""
+    import re
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"\b(hh_[a-z_0-9]+)\s*\(", txt)))
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            try:
+                build()
+            except Exception as e:  # noqa: BLE001
+                raise HHError(f"{SO} is missing and could not be built ({e}); run __graft_entry__.build()") from e
+        lib = C.CDLL(SO)
+        _sig(lib)
+        if lib.hh_abi_version() != 1:
+            raise HHError("libhhrnet.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise HHError(load().hh_last_error().decode())

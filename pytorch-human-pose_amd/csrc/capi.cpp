@@ -1,0 +1,108 @@
+// extern "C" surface declared in include/hhrnet.h (network part).
+#include <cstring>
+
+#include "../../include/hhrnet.h"
+#include "engine.h"
+
+const char *hh_get_error();
+int hh_tap_read_impl(hh_net *n, int index, float *host);
+
+extern "C" {
+
+int hh_abi_version(void) { return HH_ABI_VERSION; }
+const char *hh_last_error(void) { return hh_get_error(); }
+
+hh_net *hh_create(int num_kpts, int C, int dtype)
+{
+    if (dtype != HH_DTYPE_BF16) { hh_set_error("hh_create: only HH_DTYPE_BF16 is implemented"); return nullptr; }
+    if (num_kpts <= 0 || num_kpts > 64 || C <= 0 || C % 16) { hh_set_error("hh_create: need 0 < num_kpts <= 64 and C % 16 == 0"); return nullptr; }
+    hh_net *n = new hh_net();
+    n->K = num_kpts; n->C = C; n->dtype = dtype;
+    n->build();
+    return n;
+}
+void hh_destroy(hh_net *net) { delete net; }
+
+int hh_num_params(const hh_net *net) { return (int)net->params.size(); }
+const char *hh_param_name(const hh_net *net, int i) { return (i >= 0 && i < (int)net->params.size()) ? net->params[i].name.c_str() : nullptr; }
+int hh_param_shape(const hh_net *net, int i, int64_t shape[4])
+{
+    if (i < 0 || i >= (int)net->params.size()) return -1;
+    const auto &s = net->params[i].shape;
+    for (size_t d = 0; d < s.size(); ++d) shape[d] = s[d];
+    return (int)s.size();
+}
+
+int hh_load_weights(hh_net *net, const char *name, const float *host, const int64_t *shape, int ndim)
+{
+    auto it = net->param_index.find(name);
+    if (it == net->param_index.end()) { hh_set_error(std::string("hh_load_weights: unexpected key ") + name); return 1; }
+    ParamSlot &p = net->params[it->second];
+    if (p.counter) { p.loaded = true; return 0; }
+    if (ndim != (int)p.shape.size()) { hh_set_error(std::string("hh_load_weights: rank mismatch for ") + name); return 1; }
+    size_t n = 1;
+    for (int d = 0; d < ndim; ++d) {
+        if (shape[d] != p.shape[d]) { hh_set_error(std::string("hh_load_weights: size mismatch for ") + name); return 1; }
+        n *= (size_t)shape[d];
+    }
+    p.data.assign(host, host + n);
+    p.loaded = true;
+    net->finalized = false;
+    return 0;
+}
+int hh_finalize(hh_net *net) { return net->finalize(); }
+int hh_reserve(hh_net *net, int B, int H, int W) { return net->reserve(B, H, W); }
+int64_t hh_workspace_bytes(const hh_net *net) { return net->ws_bytes; }
+
+int hh_forward(hh_net *net, const float *images, int B, int H, int W, float *init_heatmaps, float *deconv_heatmaps,
+               int use_graph, void *stream)
+{
+    if (!images || !init_heatmaps || !deconv_heatmaps) { hh_set_error("hh_forward: null buffer"); return 1; }
+    if (B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) { hh_set_error("hh_forward: H and W must be positive multiples of 32"); return 1; }
+    return net->forward(images, B, H, W, init_heatmaps, deconv_heatmaps, use_graph, (hipStream_t)stream);
+}
+double hh_forward_flops(const hh_net *net, int B, int H, int W) { return net->flops(B, H, W); }
+
+int hh_set_taps(hh_net *net, int enable) { net->taps_enabled = enable != 0; return 0; }
+int hh_num_taps(const hh_net *net) { return (int)net->taps.size(); }
+const char *hh_tap_name(const hh_net *net, int i) { return (i >= 0 && i < (int)net->taps.size()) ? net->taps[i].name.c_str() : nullptr; }
+int hh_tap_shape(const hh_net *net, int i, int64_t shape[4])
+{
+    if (i < 0 || i >= (int)net->taps.size()) return 1;
+    const TensorDesc &d = net->tensors[net->taps[i].tensor];
+    shape[0] = net->lastB; shape[1] = net->taps[i].C; shape[2] = net->lastH >> d.shift; shape[3] = net->lastW >> d.shift;
+    return 0;
+}
+int hh_tap_read(hh_net *net, int index, float *host_nchw) { return hh_tap_read_impl(net, index, host_nchw); }
+
+int hh_flip_images(const float *images, float *out, int B, int C, int H, int W, void *stream)
+{
+    HH_CHECK_HIP(launch_flip_images(images, out, B, C, H, W, (hipStream_t)stream));
+    return 0;
+}
+
+int hh_flip_merge(float *hm, int64_t hm_bstride, const float *hm_flipped, int64_t hmf_bstride, const float *tags_flipped,
+                  int64_t tf_bstride, float *tags_out, int64_t to_bstride, const int32_t *perm_host, int B, int K, int h,
+                  int w, void *stream)
+{
+    if (K > 64) { hh_set_error("hh_flip_merge: K > 64"); return 1; }
+    static thread_local int32_t *d_perm = nullptr;
+    if (!d_perm) HH_CHECK_HIP(hipMalloc((void **)&d_perm, 64 * sizeof(int32_t)));
+    HH_CHECK_HIP(hipMemcpyAsync(d_perm, perm_host, K * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HH_CHECK_HIP(launch_flip_merge(hm, hm_bstride, hm_flipped, hmf_bstride, tags_flipped, tf_bstride, tags_out, to_bstride,
+                                   d_perm, B, K, h, w, (hipStream_t)stream));
+    return 0;
+}
+
+int hh_transform_coords(const float *xy_in, int n, double cx, double cy, double scale_w, double dst_w, double dst_h,
+                        double *xy_out)
+{
+    const double r = scale_w / dst_w;
+    for (int i = 0; i < n; ++i) {
+        xy_out[2 * i + 0] = ((double)xy_in[2 * i + 0] - dst_w * 0.5) * r + cx;
+        xy_out[2 * i + 1] = ((double)xy_in[2 * i + 1] - dst_h * 0.5) * r + cy;
+    }
+    return 0;
+}
+
+}  // extern "C"

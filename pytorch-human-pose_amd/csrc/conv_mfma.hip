@@ -1,0 +1,206 @@
+// Implicit-GEMM convolution on gfx950 matrix cores (v_mfma_f32_32x32x16_bf16), NHWC bf16.
+//
+// Replaces the ATen conv2d / conv_transpose2d + batch_norm + relu + add chain the
+// reference dispatches per layer (hrnet.py:38-45,83-100,190,202,254,265,354-356;
+// higher_hrnet.py:21-29,38,52 -- SURVEY.md §2a K1-K7,K9).  BatchNorm is folded into the
+// weights/bias at load time; bias, residual add, ReLU and the bf16 (or fp32 NCHW) store
+// are fused into the epilogue.
+//
+// Mapping (one 256-thread workgroup = 4 waves):
+//   * output tile  = TH x TW pixels of one image  x  COUT_T output channels
+//   * MFMA roles   : A = weights   (rows = 32 output channels, k = 16 input channels)
+//                    B = pixels    (cols = 32 output pixels,  k = 16 input channels)
+//                    D[cout][pixel]: lane = pixel, 16 regs = 4 groups of 4 consecutive couts
+//                    -> every lane stores 8-byte runs of channels of ITS pixel (NHWC friendly).
+//   * K loop       : input-channel chunks of KC; per chunk the (TH-1)*S+KS x (TW-1)*S+KS
+//                    input patch (all taps share it) and the chunk's weights are staged in LDS.
+//   * LDS layout   : patch pixel stride = 2*KC + 16 bytes -> odd number of 16-B slots, so the
+//                    32 lanes of a ds_read_b128 B-fragment (consecutive pixels) hit distinct
+//                    bank groups; weights are [tap][KC/8][COUT_T][8] so an A-fragment read is
+//                    512 contiguous bytes per half-wave.
+#include "kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b)
+{
+    f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+template <int KS, int S, int KC, int NT, int WC, int PT, int TW>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
+{
+    constexpr int RPT = 32 / TW;  // image rows covered by one 32-pixel MFMA column tile
+    constexpr int WP = 4 / WC;    // waves along pixels
+    constexpr int TH = WP * PT * RPT;
+    constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
+    constexpr int PS = KC * 2 + 16;  // bytes per staged pixel
+    constexpr int C8 = KC / 8;
+    constexpr int COUT_T = 32 * NT * WC;
+    constexpr int PATCH_BYTES = (PH * PW * PS + 15) & ~15;
+    constexpr int W_UNITS = KS * KS * C8 * COUT_T;  // 16-byte units of one weight chunk
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *lds_p = smem;
+    char *lds_w = smem + PATCH_BYTES;
+
+    int bid = blockIdx.x;
+    const int cg = bid % p.ncg; bid /= p.ncg;
+    const int tx = bid % p.tiles_x; bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int b = bid / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - p.pad_y, ix0 = ox0 * S - p.pad_x;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int wp = wave / WC, wc = wave % WC;
+    const int dy = r / TW, dx = r % TW;
+
+    f32x16 acc[NT][PT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][pt][i] = 0.f;
+
+    const int nchunks = p.cin / KC;
+    const bf16_raw *in_b = p.in + (size_t)b * p.Hin * p.Win * p.in_cs + p.in_coff;
+    const uint4 *w_cg = reinterpret_cast<const uint4 *>(p.w) + (size_t)cg * nchunks * W_UNITS;
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk) __syncthreads();
+        // ---- stage the input patch (zero outside the image = conv padding)
+        for (int u = tid; u < PH * PW * C8; u += 256) {
+            const int pix = u / C8, part = u % C8;
+            const int py = pix / PW, px = pix % PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
+                v = *reinterpret_cast<const uint4 *>(in_b + ((size_t)iy * p.Win + ix) * p.in_cs + chunk * KC + part * 8);
+            *reinterpret_cast<uint4 *>(lds_p + pix * PS + part * 16) = v;
+        }
+        // ---- stage this chunk's weights (already in LDS order in HBM)
+        const uint4 *wsrc = w_cg + (size_t)chunk * W_UNITS;
+        for (int u = tid; u < W_UNITS; u += 256) reinterpret_cast<uint4 *>(lds_w)[u] = wsrc[u];
+        __syncthreads();
+
+        // ---- MFMA over taps x 16-channel k-steps
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                for (int kk = 0; kk < KC / 16; ++kk) {
+                    bf16x8 a[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int unit = (((ky * KS + kx) * C8 + kk * 2 + h) * COUT_T) + (wc * NT + nt) * 32 + r;
+                        a[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(lds_w + unit * 16));
+                    }
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        const int row = (wp * PT + pt) * RPT + dy;
+                        const int addr = ((row * S + ky) * PW + dx * S + kx) * PS + kk * 32 + h * 16;
+                        const bf16x8 bv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(lds_p + addr));
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt], bv, acc[nt][pt], 0, 0, 0);
+                    }
+                }
+    }
+
+    // ---- epilogue: bias (+ residual) (+ ReLU) -> bf16 NHWC and/or fp32 NCHW
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int oy = oy0 + (wp * PT + pt) * RPT + dy, ox = ox0 + dx;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const int Y = oy * p.osy + p.ooy, X = ox * p.osx + p.oox;
+        const size_t pix = ((size_t)b * p.Hob + Y) * p.Wob + X;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 8 * g + 4 * h;
+                const float4 bs = *reinterpret_cast<const float4 *>(p.bias + c0);
+                float v0 = acc[nt][pt][4 * g + 0] + bs.x, v1 = acc[nt][pt][4 * g + 1] + bs.y;
+                float v2 = acc[nt][pt][4 * g + 2] + bs.z, v3 = acc[nt][pt][4 * g + 3] + bs.w;
+                if (p.res && c0 < p.cout_store) {
+                    const uint2 rv = *reinterpret_cast<const uint2 *>(p.res + pix * p.res_cs + p.res_coff + c0);
+                    v0 += bf16_lo(rv.x); v1 += bf16_hi(rv.x); v2 += bf16_lo(rv.y); v3 += bf16_hi(rv.y);
+                }
+                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (p.out && c0 < p.cout_store) {
+                    uint2 o; o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+                    *reinterpret_cast<uint2 *>(p.out + pix * p.out_cs + p.out_coff + c0) = o;
+                }
+                if (p.out_f32) {
+                    const size_t plane = (size_t)p.Hob * p.Wob;
+                    float *o = p.out_f32 + ((size_t)b * p.cout_real + c0) * plane + (size_t)Y * p.Wob + X;
+                    if (c0 + 0 < p.cout_real) o[0] = v0;
+                    if (c0 + 1 < p.cout_real) o[plane] = v1;
+                    if (c0 + 2 < p.cout_real) o[2 * plane] = v2;
+                    if (c0 + 3 < p.cout_real) o[3 * plane] = v3;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Instantiation table. {KS, S, KC, NT, WC, PT, TW}
+#define CONV_CONFIGS(X)                                                                             \
+    X(3, 1, 32, 1, 1, 4, 32) /* 0: 3x3 s1, Cout tile 32, 16x32 px  (C=32 branches, deconv head) */ \
+    X(3, 1, 32, 2, 1, 2, 32) /* 1: 3x3 s1, Cout tile 64,  8x32 px  (C=64/128 branches)          */ \
+    X(3, 1, 32, 2, 1, 1, 16) /* 2: 3x3 s1, Cout tile 64,  8x16 px  (16x16 maps)                 */ \
+    X(3, 1, 16, 1, 1, 2, 32) /* 3: 3x3 s1, KC 16 fallback (Cin % 32 != 0, e.g. W48)             */ \
+    X(3, 1, 16, 2, 1, 1, 16) /* 4: same, narrow maps                                            */ \
+    X(3, 2, 16, 2, 1, 1, 32) /* 5: 3x3 s2, Cout tile 64,  4x32 px                               */ \
+    X(3, 2, 16, 1, 1, 1, 32) /* 6: 3x3 s2, Cout tile 32                                         */ \
+    X(3, 2, 16, 2, 1, 1, 16) /* 7: 3x3 s2, narrow maps                                          */ \
+    X(3, 2, 16, 1, 1, 1, 16) /* 8                                                               */ \
+    X(1, 1, 32, 2, 1, 2, 32) /* 9: 1x1, Cout tile 64, 8x32 px                                   */ \
+    X(1, 1, 32, 1, 1, 4, 32) /* 10: 1x1, Cout tile 32, 16x32 px                                 */ \
+    X(1, 1, 32, 2, 1, 1, 16) /* 11: 1x1 narrow maps                                             */ \
+    X(1, 1, 32, 1, 1, 1, 16) /* 12                                                              */ \
+    X(1, 1, 16, 2, 1, 2, 32) /* 13: 1x1 KC 16 fallback                                          */ \
+    X(1, 1, 16, 1, 1, 2, 32) /* 14                                                              */ \
+    X(2, 1, 16, 1, 1, 4, 32) /* 15: 2x2 phase of the 4x4 s2 transposed conv, Cout tile 32       */ \
+    X(2, 1, 16, 2, 1, 2, 32) /* 16: same, Cout tile 64 (W48: C=48 -> 64)                        */
+
+#define CFG_ROW(ks, s, kc, nt, wc, pt, tw) {ks, s, kc, nt, wc, pt, tw},
+static const ConvConfig g_configs[] = {CONV_CONFIGS(CFG_ROW)};
+#undef CFG_ROW
+
+typedef void (*conv_fn)(const ConvParams);
+#define CFG_FN(ks, s, kc, nt, wc, pt, tw) conv_mfma_kernel<ks, s, kc, nt, wc, pt, tw>,
+static const conv_fn g_fns[] = {CONV_CONFIGS(CFG_FN)};
+#undef CFG_FN
+
+int conv_num_configs() { return (int)(sizeof(g_configs) / sizeof(g_configs[0])); }
+const ConvConfig &conv_config(int i) { return g_configs[i]; }
+
+hipError_t conv_init()
+{
+    for (int i = 0; i < conv_num_configs(); ++i) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(g_fns[i]),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_configs[i].lds_bytes());
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t conv_launch(int cfg_index, const ConvParams &p, hipStream_t stream)
+{
+    const ConvConfig &c = g_configs[cfg_index];
+    const unsigned grid = (unsigned)p.B * p.tiles_y * p.tiles_x * p.ncg;
+    hipLaunchKernelGGL(g_fns[cfg_index], dim3(grid), dim3(256), c.lds_bytes(), stream, p);
+    return hipGetLastError();
+}

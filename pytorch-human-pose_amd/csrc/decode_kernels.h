@@ -1,0 +1,41 @@
+// Launch interface of the decode kernels (heatmap aggregation, NMS/top-k, tag grouping,
+// adjust, refine).  All index/float results are bit-exact restatements of
+// /root/reference/src/keypoints/{results.py:225-234, grouping.py:80-283}.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HH_MAX_EMB 4
+#define HH_MAX_PEOPLE 32  // one wave column per candidate / group in the matching kernel
+#define HH_NMS_TILE 64
+
+// Where the full-resolution maps come from.
+//  mode 0: computed on the fly -- heat = bilinear x2 of `avg` (the stage-averaged 1/2-res map),
+//          tags = bilinear x4 of the 1/4-res tag maps; nothing full-res is ever stored in HBM.
+//  mode 1: explicit full-res arrays (the MPPEHeatmapParser.parse boundary).
+struct DecodeSrc {
+    int mode;
+    const float *avg;                  // [B,K,H/2,W/2]
+    const float *tags_q[HH_MAX_EMB];   // each [B,K,H/4,W/4], batch stride tags_bs[e]
+    int64_t tags_bs[HH_MAX_EMB];
+    const float *hm_full;              // [B,K,H,W]
+    const float *tags_full;            // [B,K,H,W,E]
+    int B, K, H, W, E;
+};
+
+hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, int B,
+                                int K, int hq, int wq, hipStream_t s);
+// per (b,k,tile): top-M candidates of the NMS'ed map as sortable keys + exact values
+hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, unsigned long long *cand_key, float *cand_val, hipStream_t s);
+// per (b,k): merge the tiles' candidates -> scores_k, coords_k (x,y), tags_k
+hipError_t launch_topk_merge(const DecodeSrc &src, int M, int ntiles, unsigned long long *cand_key, const float *cand_val,
+                             float *tags_k, int32_t *coords_k, float *scores_k, hipStream_t s);
+// per image: match_by_tag (+ the "no group" fallback); joints [B,M,K,3+E], num_people [B]
+hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const float *scores_k, int B, int K, int M, int E,
+                        double det_thr, double tag_thr, float *joints, int32_t *num_people, float *ws_tags, int32_t *status,
+                        hipStream_t s);
+// per image: quarter-pixel adjust (optional) and person scores
+hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, float *joints, const int32_t *num_people, float *scores,
+                                hipStream_t s);
+// refine: mean tag per person, then full-map argmax for every missing joint
+hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev, hipStream_t s);

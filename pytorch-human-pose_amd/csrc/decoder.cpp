@@ -1,0 +1,133 @@
+// Host side of the decode path: workspace + launch sequence behind hh_decode / hh_parse.
+#include <cstring>
+#include <vector>
+
+#include "../../include/hhrnet.h"
+#include "decode_kernels.h"
+#include "engine.h"
+
+struct hh_decoder {
+    int K, M;
+    double det_thr, tag_thr;
+    // reserved capacity
+    int rB = 0, rH = 0, rW = 0, rE = 0;
+    float *avg = nullptr, *cand_val = nullptr, *tags_k = nullptr, *scores_k = nullptr, *ws_tags = nullptr, *ws_prev = nullptr;
+    unsigned long long *cand_key = nullptr;
+    int32_t *coords_k = nullptr, *status = nullptr;
+    std::vector<void *> allocs;
+    int lastB = 0, lastE = 0;
+    void release()
+    {
+        for (void *p : allocs) hipFree(p);
+        allocs.clear();
+        rB = rH = rW = rE = 0;
+    }
+    int reserve(int B, int H, int W, int E);
+    int run(DecodeSrc &src, int adjust, int refine, float *joints, float *scores, int32_t *num_people, hipStream_t s);
+};
+
+static int ntiles_of(int H, int W)
+{
+    return ((H + HH_NMS_TILE - 1) / HH_NMS_TILE) * ((W + HH_NMS_TILE - 1) / HH_NMS_TILE);
+}
+
+int hh_decoder::reserve(int B, int H, int W, int E)
+{
+    if (B <= rB && H * W <= rH * rW && ntiles_of(H, W) <= ntiles_of(rH, rW) && E <= rE) return 0;
+    const int nB = std::max(B, rB), nH = std::max(H, rH), nW = std::max(W, rW), nE = std::max(E, rE);
+    release();
+    auto alloc = [&](size_t bytes, void **out) -> int {
+        HH_CHECK_HIP(hipMalloc(out, bytes));
+        allocs.push_back(*out);
+        return 0;
+    };
+    const size_t nt = (size_t)ntiles_of(nH, nW);
+    if (alloc((size_t)nB * K * (nH / 2) * (nW / 2) * 4, (void **)&avg)) return 1;
+    if (alloc((size_t)nB * K * nt * M * 8, (void **)&cand_key)) return 1;
+    if (alloc((size_t)nB * K * nt * M * 4, (void **)&cand_val)) return 1;
+    if (alloc((size_t)nB * K * M * nE * 4, (void **)&tags_k)) return 1;
+    if (alloc((size_t)nB * K * M * 2 * 4, (void **)&coords_k)) return 1;
+    if (alloc((size_t)nB * K * M * 4, (void **)&scores_k)) return 1;
+    if (alloc((size_t)nB * M * (K + 1) * nE * 4, (void **)&ws_tags)) return 1;
+    if (alloc((size_t)nB * M * (HH_MAX_EMB + 1) * 4, (void **)&ws_prev)) return 1;
+    if (alloc(64, (void **)&status)) return 1;
+    HH_CHECK_HIP(hipMemset(status, 0, 64));
+    rB = nB; rH = nH; rW = nW; rE = nE;
+    return 0;
+}
+
+int hh_decoder::run(DecodeSrc &src, int adjust, int refine, float *joints, float *scores, int32_t *num_people, hipStream_t s)
+{
+    src.K = K;
+    const int nt = ntiles_of(src.H, src.W);
+    HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, s));
+    HH_CHECK_HIP(launch_topk_merge(src, M, nt, cand_key, cand_val, tags_k, coords_k, scores_k, s));
+    HH_CHECK_HIP(launch_match(tags_k, coords_k, scores_k, src.B, K, M, src.E, det_thr, tag_thr, joints, num_people, ws_tags, status, s));
+    HH_CHECK_HIP(launch_adjust_scores(src, M, adjust, joints, num_people, scores, s));
+    if (refine) HH_CHECK_HIP(launch_refine(src, M, joints, num_people, ws_prev, s));
+    lastB = src.B; lastE = src.E;
+    return 0;
+}
+
+extern "C" {
+
+hh_decoder *hh_decoder_create(int num_kpts, int max_people, double det_thr, double tag_thr)
+{
+    if (num_kpts <= 0 || num_kpts > 64 || max_people <= 0 || max_people > HH_MAX_PEOPLE) {
+        hh_set_error("hh_decoder_create: need 0 < num_kpts <= 64 and 0 < max_people <= 32");
+        return nullptr;
+    }
+    hh_decoder *d = new hh_decoder();
+    d->K = num_kpts; d->M = max_people; d->det_thr = det_thr; d->tag_thr = tag_thr;
+    return d;
+}
+void hh_decoder_destroy(hh_decoder *dec)
+{
+    if (!dec) return;
+    dec->release();
+    delete dec;
+}
+int hh_decoder_reserve(hh_decoder *dec, int B, int H, int W, int E) { return dec->reserve(B, H, W, E); }
+
+int hh_decode(hh_decoder *dec, const float *hm_q, int64_t hm_q_bstride, const float *hm_h, int64_t hm_h_bstride,
+              const float *const *tags_q, const int64_t *tags_bstride, int E, int B, int hq, int wq, int adjust, int refine,
+              float *joints, float *scores, int32_t *num_people, void *stream)
+{
+    if (E < 1 || E > HH_MAX_EMB) { hh_set_error("hh_decode: 1 <= E <= 4"); return 1; }
+    if (B <= 0 || hq <= 0 || wq <= 0 || (size_t)hq * wq * 16 >= (1u << 24)) { hh_set_error("hh_decode: bad shape (need H*W < 2^24)"); return 1; }
+    const int H = 4 * hq, W = 4 * wq;
+    if (dec->reserve(B, H, W, E)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    HH_CHECK_HIP(launch_stage_average(hm_q, hm_q_bstride, hm_h, hm_h_bstride, dec->avg, B, dec->K, hq, wq, s));
+    DecodeSrc src{};
+    src.mode = 0; src.avg = dec->avg; src.B = B; src.H = H; src.W = W; src.E = E;
+    for (int e = 0; e < E; ++e) { src.tags_q[e] = tags_q[e]; src.tags_bs[e] = tags_bstride[e]; }
+    return dec->run(src, adjust, refine, joints, scores, num_people, s);
+}
+
+int hh_parse(hh_decoder *dec, const float *hm_full, const float *tags_full, int E, int B, int H, int W, int adjust, int refine,
+             float *joints, float *scores, int32_t *num_people, void *stream)
+{
+    if (E < 1 || E > HH_MAX_EMB) { hh_set_error("hh_parse: 1 <= E <= 4"); return 1; }
+    if (B <= 0 || H <= 0 || W <= 0 || (size_t)H * W >= (1u << 24)) { hh_set_error("hh_parse: bad shape (need H*W < 2^24)"); return 1; }
+    if (dec->reserve(B, H, W, E)) return 1;
+    DecodeSrc src{};
+    src.mode = 1; src.hm_full = hm_full; src.tags_full = tags_full; src.B = B; src.H = H; src.W = W; src.E = E;
+    return dec->run(src, adjust, refine, joints, scores, num_people, (hipStream_t)stream);
+}
+
+int hh_decoder_read_topk(hh_decoder *dec, float *tags_k, int32_t *coords_k, float *scores_k)
+{
+    if (!dec->lastB) { hh_set_error("hh_decoder_read_topk: nothing decoded yet"); return 1; }
+    HH_CHECK_HIP(hipDeviceSynchronize());
+    const size_t n = (size_t)dec->lastB * dec->K * dec->M;
+    HH_CHECK_HIP(hipMemcpy(tags_k, dec->tags_k, n * dec->lastE * 4, hipMemcpyDeviceToHost));
+    HH_CHECK_HIP(hipMemcpy(coords_k, dec->coords_k, n * 2 * 4, hipMemcpyDeviceToHost));
+    HH_CHECK_HIP(hipMemcpy(scores_k, dec->scores_k, n * 4, hipMemcpyDeviceToHost));
+    int32_t st = 0;
+    HH_CHECK_HIP(hipMemcpy(&st, dec->status, 4, hipMemcpyDeviceToHost));
+    if (st) { hh_set_error("decode: assignment solver hit its iteration guard"); return 1; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,577 @@
+// Plan builder + executor for HigherHRNet (see engine.h).  The layer graph restates
+// /root/reference/src/keypoints/architectures/{hrnet.py:342-385, higher_hrnet.py:47-81} as
+// a flat list of fused launches; parameter names are the reference's state-dict keys.
+#include "engine.h"
+
+#include <cmath>
+#include <cstring>
+
+static thread_local std::string g_err;
+void hh_set_error(const std::string &msg) { g_err = msg; }
+const char *hh_get_error() { return g_err.c_str(); }
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static inline bf16_raw f2bf(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_raw)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_raw)(u >> 16);
+}
+static inline float bf2f(bf16_raw h)
+{
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// ------------------------------------------------------------------------- parameters
+int hh_net::add_param(const std::string &name, std::vector<int64_t> shape, bool counter)
+{
+    ParamSlot p;
+    p.name = name;
+    p.shape = std::move(shape);
+    p.counter = counter;
+    param_index[name] = (int)params.size();
+    params.push_back(std::move(p));
+    return (int)params.size() - 1;
+}
+
+namespace {
+struct Builder {
+    hh_net &n;
+    explicit Builder(hh_net &net) : n(net) {}
+
+    // ---- parameter registration in the reference's state_dict order
+    void p_conv(const std::string &name, int cin, int cout, int k, bool bias = false)
+    {
+        n.add_param(name + ".weight", {cout, cin, k, k});
+        if (bias) n.add_param(name + ".bias", {cout});
+    }
+    void p_bn(const std::string &name, int c)
+    {
+        n.add_param(name + ".weight", {c});
+        n.add_param(name + ".bias", {c});
+        n.add_param(name + ".running_mean", {c});
+        n.add_param(name + ".running_var", {c});
+        n.add_param(name + ".num_batches_tracked", {}, true);
+    }
+
+    void register_params()
+    {
+        const int C = n.C, K = n.K;
+        const int w[4] = {C, 2 * C, 4 * C, 8 * C};
+        const std::string bb = "backbone";
+        p_conv(bb + ".conv1", 3, 64, 3); p_bn(bb + ".bn1", 64);
+        p_conv(bb + ".conv2", 64, 64, 3); p_bn(bb + ".bn2", 64);
+        const int nblocks[4] = {1, 1, 4, 3};
+        for (int s = 0; s < 4; ++s) {
+            const std::string sp = bb + ".stages." + std::to_string(s);
+            const int nsc = s == 0 ? 1 : s + 1;
+            for (int b = 0; b < nblocks[s]; ++b) {
+                const std::string hp = sp + ".blocks." + std::to_string(2 * b);
+                for (int i = 0; i < nsc; ++i)
+                    for (int u = 0; u < 4; ++u) {
+                        const std::string up = hp + ".scales_blocks." + std::to_string(i) + "." + std::to_string(u);
+                        if (s == 0) {
+                            const int cin = u == 0 ? 64 : 256;
+                            p_conv(up + ".conv1", cin, 64, 1); p_bn(up + ".bn1", 64);
+                            p_conv(up + ".conv2", 64, 64, 3); p_bn(up + ".bn2", 64);
+                            p_conv(up + ".conv3", 64, 256, 1); p_bn(up + ".bn3", 256);
+                            if (u == 0) { p_conv(up + ".downsample.0", 64, 256, 1); p_bn(up + ".downsample.1", 256); }
+                        } else {
+                            p_conv(up + ".conv1", w[i], w[i], 3); p_bn(up + ".bn1", w[i]);
+                            p_conv(up + ".conv2", w[i], w[i], 3); p_bn(up + ".bn2", w[i]);
+                        }
+                    }
+                if (s > 0) {
+                    const std::string fp = sp + ".blocks." + std::to_string(2 * b + 1);
+                    const bool last = s == 3 && b == nblocks[s] - 1;
+                    const int nout = last ? 1 : nsc;
+                    for (int i = 0; i < nout; ++i)
+                        for (int j = 0; j < nsc; ++j) {
+                            const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
+                            if (j > i) { p_conv(lp + ".0", w[j], w[i], 1); p_bn(lp + ".1", w[i]); }
+                            else if (j < i)
+                                for (int k = 0; k < i - j; ++k) {
+                                    const int co = k == i - j - 1 ? w[i] : w[j];
+                                    p_conv(lp + "." + std::to_string(k) + ".0", w[j], co, 3);
+                                    p_bn(lp + "." + std::to_string(k) + ".1", co);
+                                }
+                        }
+                }
+            }
+            if (s < 3) {
+                const std::string tp = sp + ".transition_layer.transition_blocks";
+                if (s == 0) {
+                    p_conv(tp + ".0.0", 256, w[0], 3); p_bn(tp + ".0.1", w[0]);
+                    p_conv(tp + ".1.0", 256, w[1], 3); p_bn(tp + ".1.1", w[1]);
+                } else {
+                    const std::string q = tp + "." + std::to_string(nsc);
+                    p_conv(q + ".0", w[nsc - 1], w[nsc], 3); p_bn(q + ".1", w[nsc]);
+                }
+            }
+        }
+        p_conv("init_heatmaps_head", C, 2 * K, 1, true);
+        const std::string dp = "deconv_layers.0";
+        n.add_param(dp + ".deconv.0.weight", {C + 2 * K, C, 4, 4});
+        p_bn(dp + ".deconv.1", C);
+        for (int r = 0; r < 4; ++r) {
+            const std::string rp = dp + ".resid_blocks." + std::to_string(r);
+            p_conv(rp + ".conv1", C, C, 3); p_bn(rp + ".bn1", C);
+            p_conv(rp + ".conv2", C, C, 3); p_bn(rp + ".bn2", C);
+        }
+        p_conv(dp + ".final_layer", C, K, 1, true);
+    }
+
+    // ---- plan helpers
+    int T(int C, int shift, bool zero = false)
+    {
+        TensorDesc t;
+        t.C = C; t.shift = shift; t.zero_init = zero;
+        n.tensors.push_back(t);
+        return (int)n.tensors.size() - 1;
+    }
+    int L(const std::string &conv, const std::string &bn, int cin, int cout, int ks, int stride, const std::string &bias = "")
+    {
+        ConvLayer l;
+        l.conv = conv; l.bn = bn; l.bias = bias; l.cin = cin; l.cout = cout; l.ks = ks; l.stride = stride;
+        n.layers.push_back(l);
+        return (int)n.layers.size() - 1;
+    }
+    Op &conv(int layer, int in, int out, int relu, int res = -1)
+    {
+        Op o;
+        o.kind = OP_CONV; o.layer = layer; o.in = in; o.out = out; o.relu = relu; o.res = res;
+        n.ops.push_back(o);
+        return n.ops.back();
+    }
+    // conv + BN named "<p>.<c>" / "<p>.<b>"
+    Op &cb(const std::string &p, const char *c, const char *b, int cin, int cout, int ks, int stride, int in, int out,
+           int relu, int res = -1)
+    {
+        return conv(L(p + "." + c, p + "." + b, cin, cout, ks, stride), in, out, relu, res);
+    }
+    void tap(const std::string &name, int tensor, int C, int coff = 0)
+    {
+        TapInfo t;
+        t.name = name; t.tensor = tensor; t.coff = coff; t.C = C;
+        n.taps.push_back(t);
+        Op o;
+        o.kind = OP_TAP; o.tap = (int)n.taps.size() - 1;
+        n.ops.push_back(o);
+    }
+
+    void build_plan()
+    {
+        const int C = n.C, K = n.K;
+        const int w[4] = {C, 2 * C, 4 * C, 8 * C};
+        const std::string bb = "backbone";
+        // stem (hrnet.py:354-358,378-384)
+        const int IN = T(16, 0), S1 = T(64, 1), X = T(64, 2);
+        { Op o; o.kind = OP_INCONVERT; o.out = IN; n.ops.push_back(o); }
+        conv(L(bb + ".conv1", bb + ".bn1", 3, 64, 3, 2), IN, S1, 1);
+        conv(L(bb + ".conv2", bb + ".bn2", 64, 64, 3, 2), S1, X, 1);
+        tap("stem#0", X, 64);
+
+        // stage 0: four Bottlenecks on one scale (hrnet.py:29-74), then the 256->C / 256->2C transition
+        const int t1 = T(64, 2), t2 = T(64, 2), Y = T(256, 2), D = T(256, 2);
+        for (int u = 0; u < 4; ++u) {
+            const std::string up = bb + ".stages.0.blocks.0.scales_blocks.0." + std::to_string(u);
+            const int in = u == 0 ? X : Y, cin = u == 0 ? 64 : 256;
+            cb(up, "conv1", "bn1", cin, 64, 1, 1, in, t1, 1);
+            cb(up, "conv2", "bn2", 64, 64, 3, 1, t1, t2, 1);
+            if (u == 0) {
+                cb(up, "downsample.0", "downsample.1", 64, 256, 1, 1, X, D, 0);
+                cb(up, "conv3", "bn3", 64, 256, 1, 1, t2, Y, 1, D);
+            } else {
+                cb(up, "conv3", "bn3", 64, 256, 1, 1, t2, Y, 1, Y);
+            }
+        }
+        tap("stages.0.blocks.0#0", Y, 256);
+        tap("stages.0.blocks.1#0", Y, 256);  // single-scale fusion = ReLU of a ReLU output
+        int x[4] = {-1, -1, -1, -1}, m[4], f[4];
+        for (int i = 0; i < 4; ++i) { m[i] = T(w[i], 2 + i); f[i] = T(w[i], 2 + i); }
+        x[0] = T(w[0], 2); x[1] = T(w[1], 3);
+        {
+            const std::string tp = bb + ".stages.0.transition_layer.transition_blocks";
+            cb(tp + ".0", "0", "1", 256, w[0], 3, 1, Y, x[0], 1);
+            cb(tp + ".1", "0", "1", 256, w[1], 3, 2, Y, x[1], 1);
+        }
+        tap("stages.0#0", x[0], w[0]);
+        tap("stages.0#1", x[1], w[1]);
+
+        const int catC = round_up(C + 2 * K, 16);
+        const int CAT = T(catC, 2, true);  // [feats | init heatmaps | zero pad] = torch.cat of higher_hrnet.py:73
+
+        const int nblocks[4] = {1, 1, 4, 3};
+        for (int s = 1; s < 4; ++s) {
+            const int nsc = s + 1;
+            const std::string sp = bb + ".stages." + std::to_string(s);
+            for (int b = 0; b < nblocks[s]; ++b) {
+                // HighResolutionBlock: 4 BasicBlocks per scale (hrnet.py:77-124,154-163); conv2 adds the
+                // identity and writes in place (each lane reads the residual of the pixel it overwrites).
+                const std::string hp = sp + ".blocks." + std::to_string(2 * b);
+                for (int i = 0; i < nsc; ++i)
+                    for (int u = 0; u < 4; ++u) {
+                        const std::string up = hp + ".scales_blocks." + std::to_string(i) + "." + std::to_string(u);
+                        cb(up, "conv1", "bn1", w[i], w[i], 3, 1, x[i], m[i], 1);
+                        cb(up, "conv2", "bn2", w[i], w[i], 3, 1, m[i], x[i], 1, x[i]);
+                    }
+                for (int i = 0; i < nsc; ++i)
+                    tap("stages." + std::to_string(s) + ".blocks." + std::to_string(2 * b) + "#" + std::to_string(i), x[i], w[i]);
+                // FusionLayer (hrnet.py:166-229)
+                const std::string fp = sp + ".blocks." + std::to_string(2 * b + 1);
+                const bool last = s == 3 && b == nblocks[s] - 1;
+                const int nout = last ? 1 : nsc;
+                for (int i = 0; i < nout; ++i) {
+                    const int OUT = last ? CAT : f[i];
+                    int cur = x[i];
+                    Op up;
+                    up.kind = OP_UPADD; up.in = x[i]; up.out = OUT; up.C = w[i]; up.relu = (i == 0);
+                    for (int j = i + 1; j < nsc; ++j) {  // low -> high: 1x1 conv + BN at low res
+                        const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
+                        const int u = T(w[i], 2 + j);
+                        cb(lp, "0", "1", w[j], w[i], 1, 1, x[j], u, 0);
+                        up.up[up.nup] = u; up.up_shift[up.nup] = j - i; ++up.nup;
+                    }
+                    if (up.nup) { n.ops.push_back(up); cur = OUT; }
+                    for (int j = 0; j < i; ++j) {  // high -> low: chain of stride-2 convs, summed in the last epilogue
+                        const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
+                        int tin = x[j];
+                        for (int k = 0; k < i - j - 1; ++k) {
+                            const int tmp = T(w[j], 2 + j + k + 1);
+                            cb(lp + "." + std::to_string(k), "0", "1", w[j], w[j], 3, 2, tin, tmp, 1);
+                            tin = tmp;
+                        }
+                        cb(lp + "." + std::to_string(i - j - 1), "0", "1", w[j], w[i], 3, 2, tin, OUT, j == i - 1, cur);
+                        cur = OUT;
+                    }
+                }
+                if (!last)
+                    for (int i = 0; i < nout; ++i) std::swap(x[i], f[i]);
+                for (int i = 0; i < nout; ++i)
+                    tap("stages." + std::to_string(s) + ".blocks." + std::to_string(2 * b + 1) + "#" + std::to_string(i),
+                        last ? CAT : x[i], w[i]);
+            }
+            if (s < 3) {  // TransitionLayer: only the new lowest branch has parameters (hrnet.py:262-283)
+                const std::string q = sp + ".transition_layer.transition_blocks." + std::to_string(nsc);
+                x[nsc] = T(w[nsc], 2 + nsc);
+                cb(q, "0", "1", w[nsc - 1], w[nsc], 3, 2, x[nsc - 1], x[nsc], 1);
+                for (int i = 0; i <= nsc; ++i) tap("stages." + std::to_string(s) + "#" + std::to_string(i), x[i], w[i]);
+            } else {
+                tap("stages.3#0", CAT, w[0]);
+            }
+        }
+
+        // heads (higher_hrnet.py:52,70-79): 1x1 conv with bias -> fp32 NCHW result AND bf16 copy into CAT
+        {
+            Op &o = conv(L("init_heatmaps_head", "", C, 2 * K, 1, 1, "init_heatmaps_head.bias"), CAT, CAT, 0);
+            o.out_coff = C; o.cout_store = catC - C; o.f32_out = 1;
+        }
+        // DeconvHeatmapsHead (higher_hrnet.py:7-44): ConvTranspose2d(k4,s2,p1) = 4 phase-wise 2x2 convs
+        const std::string dp = "deconv_layers.0";
+        const int DF = T(C, 1), DM = T(C, 1);
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                const int l = L(dp + ".deconv.0", dp + ".deconv.1", C + 2 * K, C, 2, 1);
+                n.layers[l].transposed = true; n.layers[l].py = py; n.layers[l].px = px;
+                Op &o = conv(l, CAT, DF, 1);
+                o.scatter = 1;
+            }
+        for (int r = 0; r < 4; ++r) {
+            const std::string rp = dp + ".resid_blocks." + std::to_string(r);
+            cb(rp, "conv1", "bn1", C, C, 3, 1, DF, DM, 1);
+            cb(rp, "conv2", "bn2", C, C, 3, 1, DM, DF, 1, DF);
+        }
+        tap("deconv#0", DF, C);
+        {
+            Op &o = conv(L(dp + ".final_layer", "", C, K, 1, 1, dp + ".final_layer.bias"), DF, -1, 0);
+            o.f32_out = 2;
+        }
+    }
+};
+}  // namespace
+
+int hh_net::build()
+{
+    Builder b(*this);
+    b.register_params();
+    b.build_plan();
+    return 0;
+}
+
+// ------------------------------------------------------------------------- finalize
+static int family_pick(int ks, int stride, int cin_pad, int coutp, int *KC, int *NT)
+{
+    if (ks == 3 && stride == 1) *KC = (cin_pad % 32 == 0) ? 32 : 16;
+    else if (ks == 1) *KC = (cin_pad % 32 == 0) ? 32 : 16;
+    else *KC = 16;
+    *NT = (coutp % 64 == 0) ? 2 : 1;
+    for (int i = 0; i < conv_num_configs(); ++i) {
+        const ConvConfig &c = conv_config(i);
+        if (c.KS == ks && c.S == stride && c.KC == *KC && c.NT == *NT) return 0;
+    }
+    return 1;
+}
+
+int hh_net::finalize()
+{
+    for (auto &p : params)
+        if (!p.loaded && !p.counter) { hh_set_error("hh_finalize: parameter never loaded: " + p.name); return 1; }
+    HH_CHECK_HIP(conv_init());
+    auto get = [&](const std::string &name) -> const std::vector<float> & { return params[param_index.at(name)].data; };
+    for (auto &l : layers) {
+        const int cin_pad0 = round_up(l.cin, 16), coutp = round_up(l.cout, 32);
+        if (family_pick(l.ks, l.stride, cin_pad0, coutp, &l.KC, &l.NT)) {
+            hh_set_error("no kernel family for conv " + l.conv);
+            return 1;
+        }
+        l.cin_pad = round_up(l.cin, l.KC);
+        const int COUT_T = 32 * l.NT;
+        l.ncg = coutp / COUT_T;
+        const int nch = l.cin_pad / l.KC, taps = l.ks * l.ks, C8 = l.KC / 8;
+        const std::vector<float> &W = get(l.conv + ".weight");
+        std::vector<float> scale(coutp, 0.f), shift(coutp, 0.f);
+        for (int co = 0; co < l.cout; ++co) {
+            if (!l.bn.empty()) {
+                const float g = get(l.bn + ".weight")[co], bta = get(l.bn + ".bias")[co];
+                const float mu = get(l.bn + ".running_mean")[co], var = get(l.bn + ".running_var")[co];
+                const float sc = g / std::sqrt(var + 1e-5f);
+                scale[co] = sc;
+                shift[co] = bta - mu * sc;
+            } else {
+                scale[co] = 1.f;
+                shift[co] = l.bias.empty() ? 0.f : get(l.bias)[co];
+            }
+        }
+        std::vector<bf16_raw> packed((size_t)l.ncg * nch * taps * C8 * COUT_T * 8, 0);
+        size_t o = 0;
+        for (int cg = 0; cg < l.ncg; ++cg)
+            for (int ch = 0; ch < nch; ++ch)
+                for (int t = 0; t < taps; ++t) {
+                    int ky = t / l.ks, kx = t % l.ks;
+                    if (l.transposed) {  // patch row 0/1 of phase py <-> ky (see conv_mfma.hip header / DESIGN.md)
+                        ky = l.py == 0 ? (ky == 0 ? 3 : 1) : (ky == 0 ? 2 : 0);
+                        kx = l.px == 0 ? (kx == 0 ? 3 : 1) : (kx == 0 ? 2 : 0);
+                    }
+                    for (int c8 = 0; c8 < C8; ++c8)
+                        for (int ci_o = 0; ci_o < COUT_T; ++ci_o)
+                            for (int j = 0; j < 8; ++j, ++o) {
+                                const int co = cg * COUT_T + ci_o, ci = ch * l.KC + c8 * 8 + j;
+                                if (co >= l.cout || ci >= l.cin) continue;
+                                float v;
+                                if (l.transposed) v = W[(((size_t)ci * l.cout + co) * 4 + ky) * 4 + kx];
+                                else v = W[(((size_t)co * l.cin + ci) * l.ks + ky) * l.ks + kx];
+                                packed[o] = f2bf(v * scale[co]);
+                            }
+                }
+        if (l.d_w) { hipFree(l.d_w); l.d_w = nullptr; }
+        if (l.d_bias) { hipFree(l.d_bias); l.d_bias = nullptr; }
+        HH_CHECK_HIP(hipMalloc((void **)&l.d_w, packed.size() * 2));
+        HH_CHECK_HIP(hipMalloc((void **)&l.d_bias, (size_t)coutp * 4));
+        HH_CHECK_HIP(hipMemcpy(l.d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+        HH_CHECK_HIP(hipMemcpy(l.d_bias, shift.data(), (size_t)coutp * 4, hipMemcpyHostToDevice));
+    }
+    for (auto &g : graphs) hipGraphExecDestroy(g.exec);
+    graphs.clear();
+    finalized = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------- workspace
+void hh_net::release_workspace()
+{
+    for (void *p : allocs) hipFree(p);
+    allocs.clear();
+    for (auto &t : tensors) t.ptr = nullptr;
+    for (auto &t : taps) t.copy = nullptr;
+    for (auto &g : graphs) hipGraphExecDestroy(g.exec);
+    graphs.clear();
+    ws_bytes = 0;
+    rB = rH = rW = 0;
+}
+
+int hh_net::reserve(int B, int H, int W)
+{
+    if (H % 32 || W % 32 || B <= 0) { hh_set_error("hh_reserve: H and W must be positive multiples of 32"); return 1; }
+    const bool have = tensors[0].ptr && (!taps_enabled || taps.empty() || taps[0].copy);
+    if (have && B <= rB && H <= rH && W <= rW) return 0;
+    const int nB = std::max(B, rB), nH = std::max(H, rH), nW = std::max(W, rW);
+    release_workspace();
+    auto alloc = [&](size_t bytes, void **out) -> int {
+        HH_CHECK_HIP(hipMalloc(out, bytes));
+        allocs.push_back(*out);
+        ws_bytes += (int64_t)bytes;
+        return 0;
+    };
+    for (auto &t : tensors) {
+        const size_t bytes = (size_t)nB * (nH >> t.shift) * (nW >> t.shift) * t.C * 2;
+        if (alloc(bytes, (void **)&t.ptr)) return 1;
+        if (t.zero_init) HH_CHECK_HIP(hipMemset(t.ptr, 0, bytes));
+    }
+    if (taps_enabled)
+        for (auto &t : taps) {
+            const TensorDesc &d = tensors[t.tensor];
+            if (alloc((size_t)nB * (nH >> d.shift) * (nW >> d.shift) * d.C * 2, (void **)&t.copy)) return 1;
+        }
+    rB = nB; rH = nH; rW = nW;
+    return 0;
+}
+
+// ------------------------------------------------------------------------- execution
+static int pick_config(const ConvLayer &l, int Wo)
+{
+    int best = -1;
+    for (int i = 0; i < conv_num_configs(); ++i) {
+        const ConvConfig &c = conv_config(i);
+        if (c.KS != l.ks || c.S != l.stride || c.KC != l.KC || c.NT != l.NT) continue;
+        if (best < 0) best = i;
+        const bool want16 = Wo <= 16;
+        if ((c.TW == 16) == want16) return i;
+    }
+    return best;
+}
+
+int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *o2, hipStream_t s)
+{
+    for (const Op &op : ops) {
+        switch (op.kind) {
+        case OP_INCONVERT:
+            HH_CHECK_HIP(launch_in_convert(images, tensors[op.out].ptr, B, H, W, s));
+            break;
+        case OP_UPADD: {
+            UpAddParams p{};
+            const TensorDesc &b = tensors[op.in], &o = tensors[op.out];
+            p.base = b.ptr; p.base_cs = b.C; p.base_coff = 0;
+            p.nup = op.nup;
+            for (int j = 0; j < op.nup; ++j) {
+                p.up[j] = tensors[op.up[j]].ptr; p.up_cs[j] = tensors[op.up[j]].C; p.up_shift[j] = op.up_shift[j];
+            }
+            p.out = o.ptr; p.out_cs = o.C; p.out_coff = 0;
+            p.B = B; p.H = H >> b.shift; p.W = W >> b.shift; p.C = op.C; p.relu = op.relu;
+            HH_CHECK_HIP(launch_upadd(p, s));
+            break;
+        }
+        case OP_TAP: {
+            if (!taps_enabled) break;
+            const TapInfo &t = taps[op.tap];
+            const TensorDesc &d = tensors[t.tensor];
+            HH_CHECK_HIP(hipMemcpyAsync(t.copy, d.ptr, (size_t)B * (H >> d.shift) * (W >> d.shift) * d.C * 2,
+                                        hipMemcpyDeviceToDevice, s));
+            break;
+        }
+        case OP_CONV: {
+            const ConvLayer &l = layers[op.layer];
+            const TensorDesc &ti = tensors[op.in];
+            ConvParams p{};
+            p.in = ti.ptr; p.in_cs = ti.C; p.in_coff = op.in_coff;
+            p.Hin = H >> ti.shift; p.Win = W >> ti.shift;
+            p.w = l.d_w; p.bias = l.d_bias;
+            p.Ho = l.stride == 2 ? p.Hin / 2 : p.Hin;
+            p.Wo = l.stride == 2 ? p.Win / 2 : p.Win;
+            p.osy = p.osx = 1; p.ooy = p.oox = 0;
+            p.pad_y = p.pad_x = (l.ks - 1) / 2;
+            if (l.transposed) {
+                p.osy = p.osx = 2; p.ooy = l.py; p.oox = l.px;
+                p.pad_y = l.py == 0 ? 1 : 0; p.pad_x = l.px == 0 ? 1 : 0;
+            }
+            p.Hob = p.Ho * p.osy; p.Wob = p.Wo * p.osx;
+            if (op.out >= 0) {
+                const TensorDesc &to = tensors[op.out];
+                p.out = to.ptr; p.out_cs = to.C; p.out_coff = op.out_coff;
+            }
+            if (op.res >= 0) {
+                const TensorDesc &tr = tensors[op.res];
+                p.res = tr.ptr; p.res_cs = tr.C; p.res_coff = op.res_coff;
+            }
+            p.out_f32 = op.f32_out == 1 ? o1 : op.f32_out == 2 ? o2 : nullptr;
+            p.cin = l.cin_pad;
+            p.cout_real = l.cout;
+            p.cout_store = op.cout_store >= 0 ? op.cout_store : round_up(l.cout, 8);
+            p.relu = op.relu;
+            p.B = B;
+            const int cfg = pick_config(l, p.Wo);
+            const ConvConfig &c = conv_config(cfg);
+            p.tiles_x = (p.Wo + c.TW - 1) / c.TW;
+            p.tiles_y = (p.Ho + c.th() - 1) / c.th();
+            p.ncg = l.ncg;
+            HH_CHECK_HIP(conv_launch(cfg, p, s));
+            break;
+        }
+        }
+    }
+    return 0;
+}
+
+int hh_net::forward(const float *images, int B, int H, int W, float *o1, float *o2, int use_graph, hipStream_t s)
+{
+    if (!finalized) { hh_set_error("hh_forward: call hh_finalize first"); return 1; }
+    if (B > rB || H > rH || W > rW || !tensors[0].ptr || (taps_enabled && !taps.empty() && !taps[0].copy))
+        if (reserve(B, H, W)) return 1;
+    lastB = B; lastH = H; lastW = W;
+    if (!use_graph || s == nullptr || taps_enabled) return enqueue(images, B, H, W, o1, o2, s);
+    for (auto &g : graphs)
+        if (g.images == images && g.o1 == o1 && g.o2 == o2 && g.B == B && g.H == H && g.W == W) {
+            HH_CHECK_HIP(hipGraphLaunch(g.exec, s));
+            return 0;
+        }
+    hipGraph_t graph;
+    HH_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue(images, B, H, W, o1, o2, s);
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc) return rc;
+    HH_CHECK_HIP(e);
+    GraphEntry g{images, o1, o2, B, H, W, nullptr};
+    HH_CHECK_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+    hipGraphDestroy(graph);
+    if (graphs.size() >= 8) { hipGraphExecDestroy(graphs.front().exec); graphs.erase(graphs.begin()); }
+    graphs.push_back(g);
+    HH_CHECK_HIP(hipGraphLaunch(g.exec, s));
+    return 0;
+}
+
+double hh_net::flops(int B, int H, int W) const
+{
+    double macs = 0;
+    for (const Op &op : ops) {
+        if (op.kind != OP_CONV) continue;
+        const ConvLayer &l = layers[op.layer];
+        const TensorDesc &ti = tensors[op.in];
+        const double hin = H >> ti.shift, win = W >> ti.shift;
+        const double ho = l.stride == 2 ? hin / 2 : hin, wo = l.stride == 2 ? win / 2 : win;
+        // a transposed-conv phase: every input pixel meets 4 of the 16 taps per phase (16 over the 4 phases)
+        macs += ho * wo * (double)l.cin * l.cout * l.ks * l.ks;
+    }
+    return 2.0 * macs * B;
+}
+
+hh_net::~hh_net()
+{
+    release_workspace();
+    for (auto &l : layers) {
+        if (l.d_w) hipFree(l.d_w);
+        if (l.d_bias) hipFree(l.d_bias);
+    }
+}
+
+// fp32 NCHW host copy of a tap
+int hh_tap_read_impl(hh_net *n, int index, float *host)
+{
+    if (index < 0 || index >= (int)n->taps.size() || !n->taps[index].copy) { hh_set_error("hh_tap_read: no such tap / taps disabled"); return 1; }
+    const TapInfo &t = n->taps[index];
+    const TensorDesc &d = n->tensors[t.tensor];
+    const int B = n->lastB, h = n->lastH >> d.shift, w = n->lastW >> d.shift;
+    std::vector<bf16_raw> tmp((size_t)B * h * w * d.C);
+    HH_CHECK_HIP(hipDeviceSynchronize());
+    HH_CHECK_HIP(hipMemcpy(tmp.data(), t.copy, tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < t.C; ++c)
+            for (int y = 0; y < h; ++y)
+                for (int x = 0; x < w; ++x)
+                    host[(((size_t)b * t.C + c) * h + y) * w + x] = bf2f(tmp[(((size_t)b * h + y) * w + x) * d.C + t.coff + c]);
+    return 0;
+}

@@ -1,0 +1,101 @@
+// Host-side engine: builds the HigherHRNet layer plan from (num_kpts, C), owns the
+// parameters under the reference's state-dict names, folds BN, packs bf16 weights for the
+// MFMA kernels and executes the plan on a HIP stream.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+void hh_set_error(const std::string &msg);
+#define HH_CHECK_HIP(expr)                                                                             \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            hh_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                           \
+            return 1;                                                                                  \
+        }                                                                                              \
+    } while (0)
+
+struct ParamSlot {
+    std::string name;
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool loaded = false;
+    bool counter = false;  // num_batches_tracked: accepted, unused
+};
+
+struct ConvLayer {
+    std::string conv, bn, bias;  // state-dict prefixes ("" = absent)
+    int cin = 0, cout = 0, ks = 1, stride = 1;
+    bool transposed = false;
+    int py = 0, px = 0;  // phase of the transposed conv this entry implements
+    // chosen at finalize
+    int KC = 0, NT = 0, cin_pad = 0, ncg = 0;
+    bf16_raw *d_w = nullptr;
+    float *d_bias = nullptr;
+};
+
+struct TensorDesc {
+    int C = 0, shift = 0;  // spatial dims = (H >> shift, W >> shift)
+    bf16_raw *ptr = nullptr;
+    bool zero_init = false;
+};
+
+enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP };
+
+struct Op {
+    OpKind kind = OP_CONV;
+    int layer = -1;
+    int in = -1, in_coff = 0;
+    int out = -1, out_coff = 0;
+    int res = -1, res_coff = 0;
+    int relu = 0;
+    int f32_out = 0;  // 0 none, 1 = init_heatmaps, 2 = deconv_heatmaps
+    int cout_store = -1;
+    int scatter = 0;  // 1: write to (2*oy+py, 2*ox+px)
+    int up[3] = {-1, -1, -1}, up_shift[3] = {0, 0, 0}, nup = 0;
+    int C = 0;  // UPADD channel count / TAP channel count
+    int tap = -1;
+};
+
+struct TapInfo {
+    std::string name;
+    int tensor, coff, C;
+    bf16_raw *copy = nullptr;
+};
+
+struct GraphEntry {
+    const void *images;
+    void *o1, *o2;
+    int B, H, W;
+    hipGraphExec_t exec;
+};
+
+struct hh_net {
+    int K, C, dtype;
+    std::vector<ParamSlot> params;
+    std::map<std::string, int> param_index;
+    std::vector<ConvLayer> layers;
+    std::vector<TensorDesc> tensors;
+    std::vector<Op> ops;
+    std::vector<TapInfo> taps;
+    bool taps_enabled = false;
+    bool finalized = false;
+    int rB = 0, rH = 0, rW = 0;  // reserved shape
+    int lastB = 0, lastH = 0, lastW = 0;
+    int64_t ws_bytes = 0;
+    std::vector<void *> allocs;
+    std::vector<GraphEntry> graphs;
+
+    int build();
+    int add_param(const std::string &name, std::vector<int64_t> shape, bool counter = false);
+    int finalize();
+    int reserve(int B, int H, int W);
+    int enqueue(const float *images, int B, int H, int W, float *o1, float *o2, hipStream_t s);
+    int forward(const float *images, int B, int H, int W, float *o1, float *o2, int use_graph, hipStream_t s);
+    double flops(int B, int H, int W) const;
+    void release_workspace();
+    ~hh_net();
+};

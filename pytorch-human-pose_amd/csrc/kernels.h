@@ -1,0 +1,63 @@
+// Internal launch interface between the host engine and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_raw;  // storage type of a bf16 element in HBM
+
+// One convolution launch (3x3 / 1x1 / 2x2-phase-of-deconv; stride 1 or 2) on NHWC bf16.
+struct ConvParams {
+    const bf16_raw *in;   // [B, Hin, Win, in_cs]
+    int in_cs, in_coff;   // pixel stride / first channel (elements, multiples of 8)
+    int Hin, Win;
+    const bf16_raw *w;    // packed [cout_group][cin_chunk][tap][KC/8][COUT_T][8]
+    const float *bias;    // [ncg*COUT_T] folded BN shift (or conv bias), zero padded
+    const bf16_raw *res;  // optional residual, same pixel grid as `out`
+    int res_cs, res_coff;
+    bf16_raw *out;        // optional bf16 NHWC output [B, Hob, Wob, out_cs]
+    int out_cs, out_coff;
+    float *out_f32;       // optional fp32 NCHW output [B, cout_real, Hob, Wob]
+    int Hob, Wob;         // output buffer spatial dims
+    int osy, ooy, osx, oox;  // output scatter: Y = oy*osy + ooy (deconv phases use 2, phase)
+    int Ho, Wo;           // conv output grid (before scatter)
+    int cin;              // padded input channels (multiple of KC)
+    int cout_real, cout_store;
+    int relu;
+    int pad_y, pad_x;     // top/left zero padding
+    int B, tiles_x, tiles_y, ncg;
+};
+
+// Tile configuration of one kernel instantiation.
+struct ConvConfig {
+    int KS, S, KC, NT, WC, PT, TW;
+    int cout_t() const { return 32 * NT * WC; }
+    int th() const { return (4 / WC) * PT * (32 / TW); }
+    size_t lds_bytes() const {
+        int PH = (th() - 1) * S + KS, PW = (TW - 1) * S + KS;
+        size_t patch = ((size_t)PH * PW * (KC * 2 + 16) + 15) & ~(size_t)15;
+        return patch + (size_t)KS * KS * KC * cout_t() * 2;
+    }
+};
+
+// Returns the number of instantiated configs / the i-th one.
+int conv_num_configs();
+const ConvConfig &conv_config(int i);
+// Launches config `cfg_index`; the grid is B*tiles_y*tiles_x*ncg blocks of 256 threads.
+hipError_t conv_launch(int cfg_index, const ConvParams &p, hipStream_t stream);
+hipError_t conv_init();  // raises the dynamic-LDS limit of every instantiation
+
+// fp32 NCHW [B,3,H,W] -> bf16 NHWC [B,H,W,16] (channels 3..15 zero)
+hipError_t launch_in_convert(const float *in, bf16_raw *out, int B, int H, int W, hipStream_t s);
+
+// out[b,y,x,c] = act(base[b,y,x,c] + sum_j up_j[b, y>>sh_j, x>>sh_j, c]),  c in [0,C)
+struct UpAddParams {
+    const bf16_raw *base; int base_cs, base_coff;
+    const bf16_raw *up[3]; int up_cs[3]; int up_shift[3]; int nup;
+    bf16_raw *out; int out_cs, out_coff;
+    int B, H, W, C, relu;
+};
+hipError_t launch_upadd(const UpAddParams &p, hipStream_t s);
+
+hipError_t launch_flip_images(const float *in, float *out, int B, int C, int H, int W, hipStream_t s);
+hipError_t launch_flip_merge(float *hm, int64_t hm_bs, const float *hmf, int64_t hmf_bs, const float *tf, int64_t tf_bs,
+                             float *to, int64_t to_bs, const int32_t *perm_dev, int B, int K, int h, int w, hipStream_t s);

@@ -1,0 +1,131 @@
+// HBM-bound helper kernels of the forward path: input layout conversion, the fused
+// "nearest-upsample + n-way sum + ReLU" of the exchange (fusion) layers, flip TTA.
+#include "kernels.h"
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack2(float a, float b)
+{
+    f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+__device__ __forceinline__ float lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// images fp32 NCHW [B,3,H,W] (what InferenceKeypointsModel.prepare_input hands over,
+// keypoints/model.py:70-76) -> bf16 NHWC with 16 channels so the stem conv is an MFMA k-step.
+__global__ __launch_bounds__(256) void in_convert_kernel(const float *__restrict__ in, bf16_raw *__restrict__ out, int B,
+                                                         int HW)
+{
+    const size_t total = (size_t)B * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / HW, p = i % HW;
+        const float *src = in + b * 3 * HW + p;
+        uint4 v0 = make_uint4(pack2(src[0], src[HW]), pack2(src[2 * (size_t)HW], 0.f), 0, 0);
+        uint4 *dst = reinterpret_cast<uint4 *>(out + i * 16);
+        dst[0] = v0;
+        dst[1] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+hipError_t launch_in_convert(const float *in, bf16_raw *out, int B, int H, int W, hipStream_t s)
+{
+    const size_t total = (size_t)B * H * W;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(in_convert_kernel, dim3(grid), dim3(256), 0, s, in, out, B, H * W);
+    return hipGetLastError();
+}
+
+// FusionLayer.forward's low->high terms and the sum (hrnet.py:200-205,214-229): the 1x1
+// conv + BN ran at low resolution; here the nearest upsample is an index shift on read and the
+// upsampled tensors are never materialised.  One thread = 8 channels (16 B) of one pixel.
+__global__ __launch_bounds__(256) void upadd_kernel(const UpAddParams p)
+{
+    const int c8n = p.C / 8;
+    const size_t total = (size_t)p.B * p.H * p.W * c8n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        size_t pix = i / c8n;
+        const int x = (int)(pix % p.W);
+        const int y = (int)((pix / p.W) % p.H);
+        const int b = (int)(pix / ((size_t)p.W * p.H));
+        const uint4 bv = *reinterpret_cast<const uint4 *>(p.base + pix * p.base_cs + p.base_coff + c8 * 8);
+        float v[8] = {lo(bv.x), hi(bv.x), lo(bv.y), hi(bv.y), lo(bv.z), hi(bv.z), lo(bv.w), hi(bv.w)};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < p.nup) {
+                const int sh = p.up_shift[j];
+                const size_t up = ((size_t)b * (p.H >> sh) + (y >> sh)) * (p.W >> sh) + (x >> sh);
+                const uint4 u = *reinterpret_cast<const uint4 *>(p.up[j] + up * p.up_cs[j] + c8 * 8);
+                v[0] += lo(u.x); v[1] += hi(u.x); v[2] += lo(u.y); v[3] += hi(u.y);
+                v[4] += lo(u.z); v[5] += hi(u.z); v[6] += lo(u.w); v[7] += hi(u.w);
+            }
+        if (p.relu)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        *reinterpret_cast<uint4 *>(p.out + pix * p.out_cs + p.out_coff + c8 * 8) =
+            make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    }
+}
+
+hipError_t launch_upadd(const UpAddParams &p, hipStream_t s)
+{
+    const size_t total = (size_t)p.B * p.H * p.W * (p.C / 8);
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(upadd_kernel, dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// keypoints/model.py:86: torch.flip(x, [3])
+__global__ __launch_bounds__(256) void flip_images_kernel(const float *__restrict__ in, float *__restrict__ out, size_t rows,
+                                                          int W)
+{
+    const size_t total = rows * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / W;
+        const int x = (int)(i % W);
+        out[i] = in[r * W + (W - 1 - x)];
+    }
+}
+
+hipError_t launch_flip_images(const float *in, float *out, int B, int C, int H, int W, hipStream_t s)
+{
+    const size_t rows = (size_t)B * C * H;
+    unsigned grid = (unsigned)((rows * W + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(flip_images_kernel, dim3(grid), dim3(256), 0, s, in, out, rows, W);
+    return hipGetLastError();
+}
+
+// keypoints/model.py:87-93: heatmaps averaged with the un-flipped, joint-permuted second pass;
+// tags of the second pass un-flipped and permuted.  (a + b) / 2 in fp32 as torch does.
+__global__ __launch_bounds__(256) void flip_merge_kernel(float *hm, int64_t hm_bs, const float *hmf, int64_t hmf_bs,
+                                                         const float *tf, int64_t tf_bs, float *to, int64_t to_bs,
+                                                         const int32_t *__restrict__ perm, int B, int K, int h, int w)
+{
+    const size_t plane = (size_t)h * w, total = (size_t)B * K * plane;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % w);
+        const int y = (int)((i / w) % h);
+        const int k = (int)((i / plane) % K);
+        const int b = (int)(i / (plane * K));
+        const size_t src = (size_t)perm[k] * plane + (size_t)y * w + (w - 1 - x);
+        const size_t dst = (size_t)k * plane + (size_t)y * w + x;
+        if (hm) hm[b * hm_bs + dst] = (hm[b * hm_bs + dst] + hmf[b * hmf_bs + src]) / 2.0f;
+        if (to) to[b * to_bs + dst] = tf[b * tf_bs + src];
+    }
+}
+
+hipError_t launch_flip_merge(float *hm, int64_t hm_bs, const float *hmf, int64_t hmf_bs, const float *tf, int64_t tf_bs,
+                             float *to, int64_t to_bs, const int32_t *perm_dev, int B, int K, int h, int w, hipStream_t s)
+{
+    const size_t total = (size_t)B * K * h * w;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(flip_merge_kernel, dim3(grid), dim3(256), 0, s, hm, hm_bs, hmf, hmf_bs, tf, tf_bs, to, to_bs, perm_dev,
+                       B, K, h, w);
+    return hipGetLastError();
+}

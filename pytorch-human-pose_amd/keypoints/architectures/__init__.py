@@ -1,0 +1,3 @@
+from .higher_hrnet import HigherHRNet
+
+__all__ = ["HigherHRNet"]

@@ -1,0 +1,97 @@
+"""Inference wrapper with the reference's interface.
+
+Stands in for `/root/reference/src/keypoints/model.py:43-111` (`InferenceKeypointsModel`) and
+`/root/reference/src/base/model.py:155-175` (checkpoint loading: weights under
+ckpt["module"]["model"], prefixes `module.` / `_orig_mod.` / `net.` stripped).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from .. import _lib
+from .grouping import MPPEHeatmapParser
+from .results import InferenceKeypointsResult
+from .transforms_utils import COCO_FLIP_INDEX, IMAGENET_MEAN, IMAGENET_STD, resize_align_multi_scale
+
+COCO_LIMBS = [(15, 13), (13, 11), (16, 14), (14, 12), (11, 12), (5, 11), (6, 12), (5, 6), (5, 7), (6, 8), (7, 9), (8, 10),
+              (1, 2), (0, 1), (0, 2), (1, 3), (2, 4), (3, 5), (4, 6)]
+
+
+def parse_checkpoint(ckpt: dict) -> dict:
+    """utils/model.py:166-173"""
+    out = {}
+    for k, v in ckpt.items():
+        for p in ("module.", "_orig_mod.", "net."):
+            k = k.replace(p, "")
+        out[k] = v
+    return out
+
+
+class InferenceKeypointsModel:
+    limbs = COCO_LIMBS
+
+    def __init__(self, net: nn.Module, det_thr: float = 0.05, tag_thr: float = 0.5, use_flip: bool = False,
+                 input_size: int = 512, max_num_people: int = 30, device: str = "cuda:0", ckpt_path: str | None = None):
+        self.net = net.to(device)
+        self.net.eval()
+        self.device = device
+        self.input_size = input_size
+        self.det_thr, self.tag_thr = det_thr, tag_thr
+        self.max_num_people = max_num_people
+        self.use_flip = use_flip
+        self._lib = _lib.load()
+        self._parser = MPPEHeatmapParser(net.num_kpts, max_num_people, det_thr, tag_thr)
+        self._perm = np.asarray(COCO_FLIP_INDEX, np.int32)
+        if ckpt_path is not None:
+            self.load_checkpoint(ckpt_path)
+
+    def load_checkpoint(self, ckpt_path: str) -> None:
+        ckpt = torch.load(ckpt_path, map_location="cpu")
+        self.net.load_state_dict(parse_checkpoint(ckpt["module"]["model"]))
+
+    def prepare_input(self, image: np.ndarray):
+        """model.py:70-76: resize-align -> ToTensor -> Normalize -> [1,3,h,w] on device"""
+        resized, center, scale = resize_align_multi_scale(image, self.input_size, 1, 1)
+        x = (resized.astype(np.float32) / 255.0 - IMAGENET_MEAN) / IMAGENET_STD
+        x = torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))[None].to(self.device)
+        return x, center, scale
+
+    @torch.no_grad()
+    def forward_tta(self, x: Tensor) -> tuple[list[Tensor], list[Tensor]]:
+        """model.py:79-94 on a batch [B,3,h,w]: net forward (+ flipped pass, un-flip, joint permutation,
+        heatmap average). Returns ([hm_1/4, hm_1/2], [tags] or [tags, tags_flipped])."""
+        K = self.net.num_kpts
+        init, dec = self.net.forward_raw(x)
+        if not self.use_flip:
+            return [init[:, :K], dec], [init[:, K:]]
+        B, _, H, W = x.shape
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        xf = torch.empty_like(x)
+        _lib.check(self._lib.hh_flip_images(x.data_ptr(), xf.data_ptr(), B, 3, H, W, stream))
+        init_f, dec_f = self.net.forward_raw(xf)
+        tags2 = torch.empty((B, K, H // 4, W // 4), device=x.device, dtype=torch.float32)
+        hq, wq = H // 4, W // 4
+        p = self._perm.ctypes.data
+        # stage 0: heatmaps = init[:, :K] (batch stride 2K planes), tags = init[:, K:]
+        _lib.check(self._lib.hh_flip_merge(init.data_ptr(), init.stride(0), init_f.data_ptr(), init_f.stride(0),
+                                           init_f[:, K:].data_ptr(), init_f.stride(0), tags2.data_ptr(), tags2.stride(0), p, B, K,
+                                           hq, wq, stream))
+        _lib.check(self._lib.hh_flip_merge(dec.data_ptr(), dec.stride(0), dec_f.data_ptr(), dec_f.stride(0), None, 0, None, 0, p,
+                                           B, K, 2 * hq, 2 * wq, stream))
+        return [init[:, :K], dec], [init[:, K:], tags2]
+
+    @torch.no_grad()
+    def infer_batch_device(self, x: Tensor):
+        """Batched forward + decode entirely on the device -> (joints [B,M,K,3+E], scores [B,M], num_people [B])."""
+        hms, tags = self.forward_tta(x)
+        return self._parser.decode_batch_device(hms[0], hms[1], tags, adjust=True, refine=True)
+
+    def __call__(self, raw_image: np.ndarray, annot: list | None) -> InferenceKeypointsResult:
+        """model.py:78-111"""
+        x, center, scale = self.prepare_input(raw_image)
+        self.model_input_shape = tuple(x.shape[-2:])
+        hms, tags = self.forward_tta(x)
+        return InferenceKeypointsResult.from_preds(raw_image, annot, x[0], hms, tags, self.limbs, scale, center, self.det_thr,
+                                                   self.tag_thr, self.max_num_people, parser=self._parser)

@@ -1,0 +1,87 @@
+"""CPU-side checks of the product package: C-ABI surface, parameter tree, host geometry."""
+import ctypes
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, PKG
+
+
+def test_capi_exports_every_declared_symbol(pkg):
+    lib = pkg._lib.load()
+    names = pkg._lib.exported_symbols()
+    assert len(names) >= 27
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.hh_abi_version() == 1
+
+
+@pytest.mark.parametrize("C", [32, 48])
+def test_state_dict_keys_match_engine_and_reference_count(pkg, C):
+    net = pkg.HigherHRNet(17, C)
+    keys = list(net.state_dict().keys())
+    assert len(keys) == 1810
+    assert net.engine_param_names() == keys
+    n_params = sum(p.numel() for p in net.parameters())
+    assert n_params == {32: 28645331, 48: 63827139}[C]
+
+
+def test_algorithmic_flops_match_survey(pkg):
+    assert abs(pkg.HigherHRNet(17, 32).forward_flops(1, 512, 512) / 2e9 - 46.203) < 1e-3
+    assert abs(pkg.HigherHRNet(17, 48).forward_flops(1, 640, 640) / 2e9 - 149.469) < 1e-3
+
+
+def test_load_weights_is_strict(pkg):
+    lib = pkg._lib.load()
+    h = lib.hh_create(17, 32, 1)
+    a = np.zeros((64, 3, 3, 3), np.float32)
+    shape = (ctypes.c_int64 * 4)(64, 3, 3, 3)
+    assert lib.hh_load_weights(h, b"backbone.conv1.weight", a.ctypes.data, shape, 4) == 0
+    assert lib.hh_load_weights(h, b"backbone.convX.weight", a.ctypes.data, shape, 4) != 0
+    assert b"unexpected key" in lib.hh_last_error()
+    bad = (ctypes.c_int64 * 4)(64, 3, 3, 1)
+    assert lib.hh_load_weights(h, b"backbone.conv1.weight", a.ctypes.data, bad, 4) != 0
+    assert lib.hh_finalize(h) != 0 and b"never loaded" in lib.hh_last_error()
+    lib.hh_destroy(h)
+    assert not lib.hh_create(17, 33, 1) and not lib.hh_decoder_create(17, 64, 0.1, 1.0)
+
+
+def test_no_cpu_fallback(pkg):
+    net = pkg.HigherHRNet(17, 32).eval()
+    with pytest.raises(pkg._lib.HHError):
+        net(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(NotImplementedError):
+        pkg.HigherHRNet(17, 32).train()(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(pkg._lib.HHError):
+        pkg.MPPEHeatmapParser(17).parse(torch.zeros(17, 64, 64), torch.zeros(17, 64, 64, 1))
+
+
+def test_multi_scale_size_and_affine(pkg):
+    tu = importlib.import_module(PKG + ".keypoints.transforms_utils")
+    rows = json.load(open(os.path.join(GOLDEN, "multi_scale_size.json")))
+    for r in rows:
+        size, center, scale = tu.get_multi_scale_size(np.zeros((r["h"], r["w"], 3), np.uint8), r["input_size"], r["current_scale"], r["min_scale"])
+        assert list(size) == r["size"] and list(center) == r["center"] and [float(scale[0]), float(scale[1])] == r["scale"]
+    # forward and inverse matrices are inverses; centre maps to centre
+    m = tu.affine_matrix((320, 240), (660.0, 480.0), (704, 512))
+    mi = tu.affine_matrix((320, 240), (660.0, 480.0), (704, 512), inverse=True)
+    assert np.allclose(np.vstack([m, [0, 0, 1]]) @ np.vstack([mi, [0, 0, 1]]), np.eye(3), atol=1e-12)
+    assert np.allclose(m @ [320, 240, 1], [352, 256])
+    # identity warp reproduces the image; transform_coords agrees with the matrix
+    img = np.random.RandomState(0).randint(0, 255, (40, 50, 3)).astype(np.uint8)
+    assert np.array_equal(tu.warp_affine(img, np.array([[1, 0, 0], [0, 1, 0]], float), (50, 40)), img)
+    res = importlib.import_module(PKG + ".keypoints.results")
+    xy = np.array([[[10.25, 20.75], [352.0, 256.0]]], np.float32)
+    out = res.transform_coords(xy, (320, 240), (660.0, 480.0), (704, 512))
+    exp = (mi @ np.array([[10.25, 20.75, 1], [352.0, 256.0, 1]]).T).T
+    assert np.allclose(out[0], exp, atol=1e-4)
+
+
+def test_parse_checkpoint_prefixes(pkg):
+    mod = importlib.import_module(PKG + ".keypoints.model")
+    out = mod.parse_checkpoint({"module.net.backbone.conv1.weight": 1, "_orig_mod.net.init_heatmaps_head.bias": 2})
+    assert out == {"backbone.conv1.weight": 1, "init_heatmaps_head.bias": 2}
