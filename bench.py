@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Benchmark of the north-star path: HigherHRNet-W32 forward + AE decode on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input resident in HBM:
+  * hh_forward on a [32,3,512,512] fp32 batch (seeded N(0,1) images, seeded synthetic weights), then
+  * hh_decode on a batch of constructed network-output maps with 10 people per image
+    (random-weight outputs have no peaks, so decode gets constructed maps of the
+    shapes the net emits: 17x128x128 + 17x256x256 heatmaps, 17x128x128 tags).
+Multi-GPU: the path shards by image (no collective on the data path); every rank runs the same
+per-GPU batch (weak scaling), timing is barrier + synchronize on both sides, max over ranks.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live: HIP events bracket every convolution launch
+of the timed steps on the launch stream (hh_profile_*), the dominant kernel instantiation is the one with
+the largest summed time.  `cpu_baseline` times the CPU oracle (oracle/) on a bounded sample on rank 0.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+PKG = "pytorch-human-pose_amd"
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+
+
+def collect_profile(pkg, net):
+    lib = pkg._lib.load()
+    n = lib.hh_profile_count(net._h)
+    per_cfg = {}
+    cfg, flops, ms, name = C.c_int(), C.c_double(), C.c_float(), C.c_char_p()
+    for i in range(n):
+        pkg._lib.check(lib.hh_profile_get(net._h, i, C.byref(cfg), C.byref(flops), C.byref(ms), C.byref(name)))
+        d = per_cfg.setdefault(cfg.value, {"n": 0, "ms": 0.0, "flops": 0.0})
+        d["n"] += 1
+        d["ms"] += ms.value
+        d["flops"] += flops.value
+    return per_cfg
+
+
+def cpu_baseline(pkg, sd, maps, fwd_images=2, dec_images=8):
+    """The oracle (a port of the reference's path, kind="port") timed on this host."""
+    from oracle import decode as orc
+    from oracle import forward as ofw
+
+    nthreads = torch.get_num_threads()
+    x = torch.from_numpy(pkg.synth.synth_images(fwd_images, 512, 512, 0))
+    with torch.no_grad():
+        ofw.higher_hrnet(x[:1], sd, 17)  # warm-up
+        t0 = time.perf_counter()
+        ofw.higher_hrnet(x, sd, 17)
+        t_fwd = (time.perf_counter() - t0) / fwd_images
+    orc.lib()
+    t0 = time.perf_counter()
+    for i in range(dec_images):
+        hm_q, hm_h, tg = maps[i % len(maps)]
+        orc.decode(hm_q, hm_h, [tg], max_people=30, det_thr=0.05, tag_thr=0.5)
+    t_dec = (time.perf_counter() - t0) / dec_images
+    return {
+        "value": 1.0 / (t_fwd + t_dec),
+        "unit": "images/sec",
+        "cores": nthreads,
+        "kind": "port",
+        "sample": f"oracle fp32 forward on {fwd_images} images 512x512 ({nthreads} threads, {t_fwd * 1e3:.0f} ms/img) + "
+                  f"C oracle decode on {dec_images} images (1 thread, {t_dec * 1e3:.0f} ms/img), host has {os.cpu_count()} cpus",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--people", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="hipGraph replay in the timed region, no per-launch events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    pkg = importlib.import_module(PKG)
+
+    B, H, W, K = args.batch, 512, 512, 17
+    net = pkg.HigherHRNet(K, 32)
+    sd = {k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    net.to(dev).eval()
+    images = torch.from_numpy(pkg.synth.synth_images(B, H, W, seed=rank)).to(dev)
+    uniq = [pkg.synth.synth_decode_maps(K, H // 4, W // 4, args.people, seed=1000 + rank * 8 + i)[:3] for i in range(8)]
+    uniq = [(a, b, t[0]) for a, b, t in uniq]
+    hm_q = torch.from_numpy(np.stack([uniq[i % 8][0] for i in range(B)])).to(dev)
+    hm_h = torch.from_numpy(np.stack([uniq[i % 8][1] for i in range(B)])).to(dev)
+    tags = torch.from_numpy(np.stack([uniq[i % 8][2] for i in range(B)])).to(dev)
+    parser = pkg.MPPEHeatmapParser(K, 30, 0.05, 0.5)
+    lib = pkg._lib.load()
+
+    def step():
+        out = net.forward_raw(images)
+        dec = parser.decode_batch_device(hm_q, hm_h, [tags], adjust=True, refine=True)
+        return out, dec
+
+    stream = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(dev)  # hipGraph capture needs a non-default stream
+    with torch.cuda.stream(side):
+        profile = not args.no_profile
+        net.use_graph = not profile
+        for _ in range(args.warmup):
+            step()
+        side.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if profile:
+            lib.hh_profile_enable(net._h, 1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, dec = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        per_cfg = collect_profile(pkg, net) if profile else {}
+        lib.hh_profile_enable(net._h, 0)
+        # split of the step (not part of the timed region): forward alone / decode alone, graph replay
+        net.use_graph = True
+        for fn in (lambda: net.forward_raw(images), lambda: parser.decode_batch_device(hm_q, hm_h, [tags])):
+            fn()
+        parts = []
+        for fn in (lambda: net.forward_raw(images), lambda: parser.decode_batch_device(hm_q, hm_h, [tags])):
+            side.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                fn()
+            side.synchronize()
+            parts.append((time.perf_counter() - t1) / 5)
+    del stream
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    num_people = int(dec[2].sum().item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        line = {
+            "metric": "images/sec (fwd+decode) HigherHRNet-W32 512px",
+            "value": round(value, 2),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"HigherHRNet-W32 inference bf16, batch {B} @ 512x512 per GPU (conv fwd on N(0,1) images + AE decode "
+                            f"on constructed maps, {args.people} people/image, det_thr 0.05, tag_thr 0.5, adjust+refine)",
+                "global_batch": world * B,
+                "parallelism": f"image-sharded replicas x{world}, no data-path collective",
+                "people_decoded_per_batch": num_people,
+                "forward_ms": round(parts[0] * 1e3, 3),
+                "decode_ms": round(parts[1] * 1e3, 3),
+                "forward_tflops": round(net.forward_flops(B, H, W) / parts[0] / 1e12, 1),
+                "timed_region": "eager launches with per-conv HIP events" if profile else "hipGraph replay",
+            },
+        }
+        if per_cfg:
+            dom = max(per_cfg, key=lambda c: per_cfg[c]["ms"])
+            d = per_cfg[dom]
+            cfgv = (C.c_int * 7)()
+            lib.hh_conv_config(dom, cfgv)
+            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            total_ms = sum(v["ms"] for v in per_cfg.values())
+            line["roofline"] = {
+                "bound": "mfma",
+                "achieved": round(achieved, 2),
+                "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "kernel": "conv_mfma_kernel<KS=%d,S=%d,KC=%d,NT=%d,WC=%d,PT=%d,TW=%d>" % tuple(cfgv),
+                "launches": d["n"],
+                "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 2),
+                "avg_launch_gflop": round(d["flops"] / d["n"] / 1e9, 3),
+                "share_of_conv_time": round(d["ms"] / total_ms, 3),
+                "all_conv_tflops": round(sum(v["flops"] for v in per_cfg.values()) / (total_ms * 1e-3) / 1e12, 2),
+            }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pkg, sd, uniq)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,16 @@ int hh_forward(hh_net *net, const float *images, int B, int H, int W, float *ini
 /* Algorithmic conv/deconv FLOPs (2*MACs) of one forward at this shape -- SURVEY.md §8d.  */
 double hh_forward_flops(const hh_net *net, int B, int H, int W);
 
+/* Live per-launch timing for bench.py's roofline line: when enabled, hh_forward runs eagerly and brackets
+ * every convolution launch with HIP events recorded on `stream`.  hh_profile_get(i) returns the i-th
+ * launch since hh_profile_enable: kernel instantiation index, algorithmic FLOPs (2*MACs) of that launch,
+ * elapsed milliseconds, and the state-dict prefix of the layer.  hh_conv_config describes an
+ * instantiation as {KS, S, KC, NT, WC, PT, TW}.                                                       */
+int hh_profile_enable(hh_net *net, int enable);
+int hh_profile_count(const hh_net *net);
+int hh_profile_get(hh_net *net, int index, int *cfg, double *flops, float *ms, const char **layer);
+int hh_conv_config(int cfg, int out[7]);
+
 /* Debug taps (parity tests): when enabled, hh_forward copies selected intermediate
  * activations; hh_tap_read converts one to fp32 NCHW on the host. Names follow the
  * reference module paths, e.g. "stages.2.blocks.3#1" = output 1 of backbone.stages[2].blocks[3]. */

@@ -50,6 +50,10 @@ def _sig(lib):
         "hh_tap_name": (cp, [vp, i32]),
         "hh_tap_shape": (i32, [vp, i32, pi64]),
         "hh_tap_read": (i32, [vp, i32, vp]),
+        "hh_profile_enable": (i32, [vp, i32]),
+        "hh_profile_count": (i32, [vp]),
+        "hh_profile_get": (i32, [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_char_p)]),
+        "hh_conv_config": (i32, [i32, C.POINTER(C.c_int)]),
         "hh_flip_images": (i32, [vp, vp, i32, i32, i32, i32, vp]),
         "hh_flip_merge": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
         "hh_decoder_create": (vp, [i32, i32, dbl, dbl]),

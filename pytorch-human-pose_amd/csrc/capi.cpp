@@ -75,6 +75,26 @@ int hh_tap_shape(const hh_net *net, int i, int64_t shape[4])
 }
 int hh_tap_read(hh_net *net, int index, float *host_nchw) { return hh_tap_read_impl(net, index, host_nchw); }
 
+int hh_profile_enable(hh_net *net, int enable) { net->prof_enabled = enable != 0; net->prof_used = 0; return 0; }
+int hh_profile_count(const hh_net *net) { return (int)net->prof_used; }
+int hh_profile_get(hh_net *net, int i, int *cfg, double *flops, float *ms, const char **layer)
+{
+    if (i < 0 || i >= (int)net->prof_used) { hh_set_error("hh_profile_get: index out of range"); return 1; }
+    const ProfRecord &r = net->prof[i];
+    HH_CHECK_HIP(hipEventSynchronize(r.e1));
+    HH_CHECK_HIP(hipEventElapsedTime(ms, r.e0, r.e1));
+    *cfg = r.cfg; *flops = r.flops;
+    *layer = net->layers[net->ops[r.op].layer].conv.c_str();
+    return 0;
+}
+int hh_conv_config(int cfg, int out[7])
+{
+    if (cfg < 0 || cfg >= conv_num_configs()) return 1;
+    const ConvConfig &c = conv_config(cfg);
+    out[0] = c.KS; out[1] = c.S; out[2] = c.KC; out[3] = c.NT; out[4] = c.WC; out[5] = c.PT; out[6] = c.TW;
+    return 0;
+}
+
 int hh_flip_images(const float *images, float *out, int B, int C, int H, int W, void *stream)
 {
     HH_CHECK_HIP(launch_flip_images(images, out, B, C, H, W, (hipStream_t)stream));

@@ -20,10 +20,13 @@
 //                    512 contiguous bytes per half-wave.
 #include "kernels.h"
 
+#include <utility>
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP's uint4 struct kept staging arrays in scratch
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b)
 {
@@ -33,8 +36,21 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b)
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
+// Compile-time loop: indices are constant expressions in the front end, so per-thread staging arrays are
+// promoted to registers (a "#pragma unroll" loop left them in scratch: guide rule 20).
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int KS, int S, int KC, int NT, int WC, int PT, int TW>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 {
     constexpr int RPT = 32 / TW;  // image rows covered by one 32-pixel MFMA column tile
     constexpr int WP = 4 / WC;    // waves along pixels
@@ -44,7 +60,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
     constexpr int C8 = KC / 8;
     constexpr int COUT_T = 32 * NT * WC;
     constexpr int PATCH_BYTES = (PH * PW * PS + 15) & ~15;
+    constexpr int P_UNITS = PH * PW * C8;           // 16-byte units of one input patch chunk
     constexpr int W_UNITS = KS * KS * C8 * COUT_T;  // 16-byte units of one weight chunk
+    constexpr int NPL = (P_UNITS + 255) / 256, NWL = (W_UNITS + 255) / 256;
+    constexpr int OS = COUT_T * 2 + 16;             // bytes per pixel of the staged output tile
+    constexpr int O8 = COUT_T / 8;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *lds_p = smem;
@@ -64,34 +84,77 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
     const int wp = wave / WC, wc = wave % WC;
     const int dy = r / TW, dx = r % TW;
 
-    f32x16 acc[NT][PT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nt][pt][i] = 0.f;
-
     const int nchunks = p.cin / KC;
     const bf16_raw *in_b = p.in + (size_t)b * p.Hin * p.Win * p.in_cs + p.in_coff;
-    const uint4 *w_cg = reinterpret_cast<const uint4 *>(p.w) + (size_t)cg * nchunks * W_UNITS;
+    const u32x4 *w_cg = reinterpret_cast<const u32x4 *>(p.w) + (size_t)cg * nchunks * W_UNITS;
+
+    // ---- register-staged loads: every global load of a chunk is issued before any LDS write, and the
+    //      next chunk's loads are issued before the current chunk's MFMAs (latency hides under compute).
+    u32x4 preg[NPL], wreg[NWL];
+#define ISSUE_LOADS(chunk_)                                                                                        \
+    {                                                                                                              \
+        const int ch_ = (chunk_);                                                                                  \
+        static_for<NPL>([&](auto ic) {                                                                             \
+            constexpr int i = decltype(ic)::value;                                                                 \
+            const int u = tid + 256 * i;                                                                           \
+            const int pix = u / C8, part = u % C8;                                                                 \
+            const int iy = iy0 + pix / PW, ix = ix0 + pix % PW;                                                    \
+            const bool ok = u < P_UNITS && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;                         \
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(                                                    \
+                in_b + ((size_t)(ok ? iy : 0) * p.Win + (ok ? ix : 0)) * p.in_cs + ch_ * KC + part * 8);           \
+            const u32x4 v = *src; /* always-valid address; zero outside the image = conv padding */               \
+            preg[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};                                                                \
+        });                                                                                                        \
+        const u32x4 *wsrc = w_cg + (size_t)ch_ * W_UNITS;                                                          \
+        static_for<NWL>([&](auto ic) {                                                                             \
+            constexpr int i = decltype(ic)::value;                                                                 \
+            const int u = tid + 256 * i;                                                                           \
+            wreg[i] = wsrc[u < W_UNITS ? u : 0];                                                                   \
+        });                                                                                                        \
+    }
+#define WRITE_LDS()                                                                                                \
+    {                                                                                                              \
+        static_for<NPL>([&](auto ic) {                                                                             \
+            constexpr int i = decltype(ic)::value;                                                                 \
+            const int u = tid + 256 * i;                                                                           \
+            if (u < P_UNITS) *reinterpret_cast<u32x4 *>(lds_p + (u / C8) * PS + (u % C8) * 16) = preg[i];          \
+        });                                                                                                        \
+        static_for<NWL>([&](auto ic) {                                                                             \
+            constexpr int i = decltype(ic)::value;                                                                 \
+            const int u = tid + 256 * i;                                                                           \
+            if (u < W_UNITS) reinterpret_cast<u32x4 *>(lds_w)[u] = wreg[i];                                        \
+        });                                                                                                        \
+    }
+
+    ISSUE_LOADS(0);
+
+    // ---- accumulators start at bias (+ residual): the 8-byte residual gathers overlap the patch loads
+    f32x16 acc[NT][PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int oy = oy0 + (wp * PT + pt) * RPT + dy, ox = ox0 + dx;
+        const bool valid = oy < p.Ho && ox < p.Wo;
+        const size_t pix = ((size_t)b * p.Hob + (oy * p.osy + p.ooy)) * p.Wob + (ox * p.osx + p.oox);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 8 * g + 4 * h;
+                const float4 bs = *reinterpret_cast<const float4 *>(p.bias + c0);
+                float v0 = bs.x, v1 = bs.y, v2 = bs.z, v3 = bs.w;
+                if (p.res && valid && c0 < p.cout_store) {
+                    const uint2 rv = *reinterpret_cast<const uint2 *>(p.res + pix * p.res_cs + p.res_coff + c0);
+                    v0 += bf16_lo(rv.x); v1 += bf16_hi(rv.x); v2 += bf16_lo(rv.y); v3 += bf16_hi(rv.y);
+                }
+                acc[nt][pt][4 * g + 0] = v0; acc[nt][pt][4 * g + 1] = v1;
+                acc[nt][pt][4 * g + 2] = v2; acc[nt][pt][4 * g + 3] = v3;
+            }
+    }
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        if (chunk) __syncthreads();
-        // ---- stage the input patch (zero outside the image = conv padding)
-        for (int u = tid; u < PH * PW * C8; u += 256) {
-            const int pix = u / C8, part = u % C8;
-            const int py = pix / PW, px = pix % PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
-                v = *reinterpret_cast<const uint4 *>(in_b + ((size_t)iy * p.Win + ix) * p.in_cs + chunk * KC + part * 8);
-            *reinterpret_cast<uint4 *>(lds_p + pix * PS + part * 16) = v;
-        }
-        // ---- stage this chunk's weights (already in LDS order in HBM)
-        const uint4 *wsrc = w_cg + (size_t)chunk * W_UNITS;
-        for (int u = tid; u < W_UNITS; u += 256) reinterpret_cast<uint4 *>(lds_w)[u] = wsrc[u];
+        WRITE_LDS();
         __syncthreads();
+        if (chunk + 1 < nchunks) ISSUE_LOADS(chunk + 1);
 
         // ---- MFMA over taps x 16-channel k-steps
 #pragma unroll
@@ -116,33 +179,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
                             acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt], bv, acc[nt][pt], 0, 0, 0);
                     }
                 }
+        __syncthreads();  // every wave is done reading this chunk (LDS is rewritten next)
     }
 
-    // ---- epilogue: bias (+ residual) (+ ReLU) -> bf16 NHWC and/or fp32 NCHW
+    // ---- epilogue: (ReLU) -> fp32 NCHW directly, bf16 NHWC through an LDS transpose so that every
+    //      lane stores 16 contiguous bytes and a tile row leaves as one contiguous run.
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
+        const int lp = ((wp * PT + pt) * RPT + dy) * TW + dx;  // pixel index inside the tile
         const int oy = oy0 + (wp * PT + pt) * RPT + dy, ox = ox0 + dx;
-        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const bool valid = oy < p.Ho && ox < p.Wo;
         const int Y = oy * p.osy + p.ooy, X = ox * p.osx + p.oox;
-        const size_t pix = ((size_t)b * p.Hob + Y) * p.Wob + X;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 8 * g + 4 * h;
-                const float4 bs = *reinterpret_cast<const float4 *>(p.bias + c0);
-                float v0 = acc[nt][pt][4 * g + 0] + bs.x, v1 = acc[nt][pt][4 * g + 1] + bs.y;
-                float v2 = acc[nt][pt][4 * g + 2] + bs.z, v3 = acc[nt][pt][4 * g + 3] + bs.w;
-                if (p.res && c0 < p.cout_store) {
-                    const uint2 rv = *reinterpret_cast<const uint2 *>(p.res + pix * p.res_cs + p.res_coff + c0);
-                    v0 += bf16_lo(rv.x); v1 += bf16_hi(rv.x); v2 += bf16_lo(rv.y); v3 += bf16_hi(rv.y);
-                }
+                float v0 = acc[nt][pt][4 * g + 0], v1 = acc[nt][pt][4 * g + 1];
+                float v2 = acc[nt][pt][4 * g + 2], v3 = acc[nt][pt][4 * g + 3];
                 if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                if (p.out && c0 < p.cout_store) {
+                const int cl = (wc * NT + nt) * 32 + 8 * g + 4 * h;  // channel inside the WG's cout tile
+                if (p.out) {
                     uint2 o; o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
-                    *reinterpret_cast<uint2 *>(p.out + pix * p.out_cs + p.out_coff + c0) = o;
+                    *reinterpret_cast<uint2 *>(smem + lp * OS + cl * 2) = o;
                 }
-                if (p.out_f32) {
+                if (p.out_f32 && valid) {
+                    const int c0 = cg * COUT_T + cl;
                     const size_t plane = (size_t)p.Hob * p.Wob;
                     float *o = p.out_f32 + ((size_t)b * p.cout_real + c0) * plane + (size_t)Y * p.Wob + X;
                     if (c0 + 0 < p.cout_real) o[0] = v0;
@@ -152,12 +213,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
                 }
             }
     }
+    if (p.out) {
+        __syncthreads();
+        constexpr int O_UNITS = TH * TW * O8;
+#pragma unroll
+        for (int i = 0; i < (O_UNITS + 255) / 256; ++i) {
+            const int u = tid + 256 * i;
+            const int lp = u / O8, part = u % O8;
+            const int oy = oy0 + lp / TW, ox = ox0 + lp % TW;
+            const int c = cg * COUT_T + part * 8;
+            if (u < O_UNITS && oy < p.Ho && ox < p.Wo && c < p.cout_store) {
+                const size_t pix = ((size_t)b * p.Hob + (oy * p.osy + p.ooy)) * p.Wob + (ox * p.osx + p.oox);
+                *reinterpret_cast<uint4 *>(p.out + pix * p.out_cs + p.out_coff + c) =
+                    *reinterpret_cast<const uint4 *>(smem + lp * OS + part * 16);
+            }
+        }
+    }
 }
+
+#undef ISSUE_LOADS
+#undef WRITE_LDS
 
 // ---------------------------------------------------------------------------------------
 // Instantiation table. {KS, S, KC, NT, WC, PT, TW}
 #define CONV_CONFIGS(X)                                                                             \
-    X(3, 1, 32, 1, 1, 4, 32) /* 0: 3x3 s1, Cout tile 32, 16x32 px  (C=32 branches, deconv head) */ \
+    X(3, 1, 32, 1, 1, 2, 32) /* 0: 3x3 s1, Cout tile 32,  8x32 px  (C=32 branches, deconv head) */ \
     X(3, 1, 32, 2, 1, 2, 32) /* 1: 3x3 s1, Cout tile 64,  8x32 px  (C=64/128 branches)          */ \
     X(3, 1, 32, 2, 1, 1, 16) /* 2: 3x3 s1, Cout tile 64,  8x16 px  (16x16 maps)                 */ \
     X(3, 1, 16, 1, 1, 2, 32) /* 3: 3x3 s1, KC 16 fallback (Cin % 32 != 0, e.g. W48)             */ \

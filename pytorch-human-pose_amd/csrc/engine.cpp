@@ -499,7 +499,22 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             p.tiles_x = (p.Wo + c.TW - 1) / c.TW;
             p.tiles_y = (p.Ho + c.th() - 1) / c.th();
             p.ncg = l.ncg;
+            ProfRecord *pr = nullptr;
+            if (prof_enabled) {
+                if (prof_used == prof.size()) {
+                    ProfRecord r{};
+                    HH_CHECK_HIP(hipEventCreate(&r.e0));
+                    HH_CHECK_HIP(hipEventCreate(&r.e1));
+                    prof.push_back(r);
+                }
+                pr = &prof[prof_used++];
+                pr->op = (int)(&op - ops.data());
+                pr->cfg = cfg;
+                pr->flops = 2.0 * B * p.Ho * p.Wo * (double)l.cin * l.cout * l.ks * l.ks;
+                HH_CHECK_HIP(hipEventRecord(pr->e0, s));
+            }
             HH_CHECK_HIP(conv_launch(cfg, p, s));
+            if (pr) HH_CHECK_HIP(hipEventRecord(pr->e1, s));
             break;
         }
         }
@@ -513,7 +528,7 @@ int hh_net::forward(const float *images, int B, int H, int W, float *o1, float *
     if (B > rB || H > rH || W > rW || !tensors[0].ptr || (taps_enabled && !taps.empty() && !taps[0].copy))
         if (reserve(B, H, W)) return 1;
     lastB = B; lastH = H; lastW = W;
-    if (!use_graph || s == nullptr || taps_enabled) return enqueue(images, B, H, W, o1, o2, s);
+    if (!use_graph || s == nullptr || taps_enabled || prof_enabled) return enqueue(images, B, H, W, o1, o2, s);
     for (auto &g : graphs)
         if (g.images == images && g.o1 == o1 && g.o2 == o2 && g.B == B && g.H == H && g.W == W) {
             HH_CHECK_HIP(hipGraphLaunch(g.exec, s));
@@ -552,6 +567,7 @@ double hh_net::flops(int B, int H, int W) const
 hh_net::~hh_net()
 {
     release_workspace();
+    for (auto &r : prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (auto &l : layers) {
         if (l.d_w) hipFree(l.d_w);
         if (l.d_bias) hipFree(l.d_bias);

@@ -66,6 +66,12 @@ struct TapInfo {
     bf16_raw *copy = nullptr;
 };
 
+struct ProfRecord {
+    int op, cfg;
+    double flops;
+    hipEvent_t e0, e1;
+};
+
 struct GraphEntry {
     const void *images;
     void *o1, *o2;
@@ -88,6 +94,10 @@ struct hh_net {
     int64_t ws_bytes = 0;
     std::vector<void *> allocs;
     std::vector<GraphEntry> graphs;
+    // live per-launch timing (bench.py roofline): HIP events on the launch stream around every conv
+    bool prof_enabled = false;
+    std::vector<ProfRecord> prof;
+    size_t prof_used = 0;
 
     int build();
     int add_param(const std::string &name, std::vector<int64_t> shape, bool counter = false);
