@@ -9,9 +9,10 @@ One "step" = one pass of the hot path over one batch of synthetic input resident
 Multi-GPU: the path shards by image (no collective on the data path); every rank runs the same
 per-GPU batch (weak scaling), timing is barrier + synchronize on both sides, max over ranks.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live: HIP events bracket every convolution launch
-of the timed steps on the launch stream (hh_profile_*), the dominant kernel instantiation is the one with
-the largest summed time.  `cpu_baseline` times the CPU oracle (oracle/) on a bounded sample on rank 0.
+Prints ONE JSON line (rank 0).  `roofline` is measured live inside the timed region: steps 1..K-1 replay the
+captured hipGraph, the K-th (last) timed step runs eagerly with HIP events bracketing every convolution
+launch on the launch stream (hh_profile_*); the dominant kernel instantiation is the one with the largest
+summed time in that step.  `cpu_baseline` times the CPU oracle (oracle/) on a bounded sample on rank 0.
 """
 import argparse
 import ctypes as C
@@ -118,17 +119,17 @@ def main():
     side = torch.cuda.Stream(dev)  # hipGraph capture needs a non-default stream
     with torch.cuda.stream(side):
         profile = not args.no_profile
-        net.use_graph = not profile
+        net.use_graph = True
         for _ in range(args.warmup):
             step()
         side.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        if profile:
-            lib.hh_profile_enable(net._h, 1)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            if profile and i == args.steps - 1:
+                lib.hh_profile_enable(net._h, 1)  # last timed step: eager launches + per-conv HIP events
             out, dec = step()
         torch.cuda.synchronize()
         if dist is not None:
@@ -181,7 +182,7 @@ def main():
                 "forward_ms": round(parts[0] * 1e3, 3),
                 "decode_ms": round(parts[1] * 1e3, 3),
                 "forward_tflops": round(net.forward_flops(B, H, W) / parts[0] / 1e12, 1),
-                "timed_region": "eager launches with per-conv HIP events" if profile else "hipGraph replay",
+                "timed_region": "hipGraph replay; last step eager with per-conv HIP events" if profile else "hipGraph replay",
             },
         }
         if per_cfg:

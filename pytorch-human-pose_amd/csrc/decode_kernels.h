@@ -21,12 +21,16 @@ struct DecodeSrc {
     const float *hm_full;              // [B,K,H,W]
     const float *tags_full;            // [B,K,H,W,E]
     int B, K, H, W, E;
+    // torch's area_pixel_compute_scale: (float)in / (float)out, evaluated once on the host (IEEE division)
+    float scale_h2, scale_w2;  // half-res -> full-res
+    float scale_h4, scale_w4;  // quarter-res -> full-res
 };
 
 hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, int B,
                                 int K, int hq, int wq, hipStream_t s);
 // per (b,k,tile): top-M candidates of the NMS'ed map as sortable keys + exact values
-hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, unsigned long long *cand_key, float *cand_val, hipStream_t s);
+hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, unsigned long long *cand_key, float *cand_val, float *cellmax,
+                                hipStream_t s);
 // per (b,k): merge the tiles' candidates -> scores_k, coords_k (x,y), tags_k
 hipError_t launch_topk_merge(const DecodeSrc &src, int M, int ntiles, unsigned long long *cand_key, const float *cand_val,
                              float *tags_k, int32_t *coords_k, float *scores_k, hipStream_t s);
@@ -38,4 +42,5 @@ hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const floa
 hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, float *joints, const int32_t *num_people, float *scores,
                                 hipStream_t s);
 // refine: mean tag per person, then full-map argmax for every missing joint
-hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev, hipStream_t s);
+hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev,
+                         unsigned long long *ws_best, int32_t *ws_jobs, const float *cellmax, float *tagb, hipStream_t s);

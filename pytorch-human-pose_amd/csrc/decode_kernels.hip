@@ -12,9 +12,8 @@ typedef unsigned long long u64;
 // F.interpolate(mode="bilinear", align_corners=False), torch CPU fp32 (results.py:48-67)
 struct Lin { int i0, i1; float w0, w1; };
 
-__device__ __forceinline__ Lin src_index(int in_size, int out_size, int dst)
+__device__ __forceinline__ Lin src_index(int in_size, float scale, int dst)
 {
-    const float scale = __fdiv_rn((float)in_size, (float)out_size);
     float r = __builtin_fmaf(scale, (float)dst + 0.5f, -0.5f);
     if (r < 0.f) r = 0.f;
     const int a = (int)r;
@@ -38,38 +37,39 @@ __device__ __forceinline__ float heat_at(const DecodeSrc &s, int b, int k, int y
 {
     if (s.mode == 1) return s.hm_full[(((size_t)b * s.K + k) * s.H + y) * s.W + x];
     const int hh = s.H >> 1, wh = s.W >> 1;
-    return bilerp(s.avg + ((size_t)b * s.K + k) * hh * wh, wh, src_index(hh, s.H, y), src_index(wh, s.W, x));
+    return bilerp(s.avg + ((size_t)b * s.K + k) * hh * wh, wh, src_index(hh, s.scale_h2, y), src_index(wh, s.scale_w2, x));
 }
 __device__ __forceinline__ float tag_at(const DecodeSrc &s, int b, int k, int y, int x, int e)
 {
     if (s.mode == 1) return s.tags_full[((((size_t)b * s.K + k) * s.H + y) * s.W + x) * s.E + e];
     const int hq = s.H >> 2, wq = s.W >> 2;
-    return bilerp(s.tags_q[e] + (size_t)b * s.tags_bs[e] + (size_t)k * hq * wq, wq, src_index(hq, s.H, y), src_index(wq, s.W, x));
+    return bilerp(s.tags_q[e] + (size_t)b * s.tags_bs[e] + (size_t)k * hq * wq, wq, src_index(hq, s.scale_h4, y), src_index(wq, s.scale_w4, x));
 }
 
 // ------------------------------------------------------------------ stage average
 // results.py:225-226: match_heatmaps_size (1/4 -> 1/2) then torch.stack(...).mean(dim=0)
 __global__ __launch_bounds__(256) void stage_average_kernel(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs,
-                                                            float *avg, int B, int K, int hq, int wq)
+                                                            float *avg, int K, int hq, int wq, float sy, float sx)
 {
     const int hh = 2 * hq, wh = 2 * wq;
-    const size_t plane = (size_t)hh * wh, total = (size_t)B * K * plane;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int x = (int)(i % wh), y = (int)((i / wh) % hh);
-        const int k = (int)((i / plane) % K), b = (int)(i / (plane * K));
-        const float up = bilerp(hm_q + (size_t)b * hm_q_bs + (size_t)k * hq * wq, wq, src_index(hq, hh, y), src_index(wq, wh, x));
-        const float hv = hm_h[(size_t)b * hm_h_bs + (size_t)k * plane + (size_t)y * wh + x];
-        avg[i] = (up + hv) / 2.0f;
+    const int k = blockIdx.x, b = blockIdx.y, band = blockIdx.z, nband = gridDim.z;
+    const float *q = hm_q + (size_t)b * hm_q_bs + (size_t)k * hq * wq;
+    const float *hsrc = hm_h + (size_t)b * hm_h_bs + (size_t)k * hh * wh;
+    float *dst = avg + ((size_t)b * K + k) * hh * wh;
+    for (int x = threadIdx.x; x < wh; x += 256) {
+        const Lin lx = src_index(wq, sx, x);
+        for (int y = band; y < hh; y += nband) {
+            const float up = bilerp(q, wq, src_index(hq, sy, y), lx);
+            dst[(size_t)y * wh + x] = (up + hsrc[(size_t)y * wh + x]) / 2.0f;
+        }
     }
 }
 
 hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, int B,
                                 int K, int hq, int wq, hipStream_t s)
 {
-    const size_t total = (size_t)B * K * 4 * hq * wq;
-    unsigned grid = (unsigned)((total + 255) / 256);
-    if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(stage_average_kernel, dim3(grid), dim3(256), 0, s, hm_q, hm_q_bs, hm_h, hm_h_bs, avg, B, K, hq, wq);
+    const float sy = (float)hq / (float)(2 * hq), sx = (float)wq / (float)(2 * wq);
+    hipLaunchKernelGGL(stage_average_kernel, dim3(K, B, 8), dim3(256), 0, s, hm_q, hm_q_bs, hm_h, hm_h_bs, avg, K, hq, wq, sy, sx);
     return hipGetLastError();
 }
 
@@ -100,23 +100,62 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v)
 // map, computed from L2-resident low-res data; separable 5x5 max through LDS; then M rounds
 // of workgroup-wide arg-max (wave shuffles + one LDS exchange per round).
 __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src, int M, int tiles_x, u64 *__restrict__ cand_key,
-                                                            float *__restrict__ cand_val)
+                                                            float *__restrict__ cand_val, float *__restrict__ cellmax)
 {
-    constexpr int TS = HH_NMS_TILE, HS = TS + 4;
+    constexpr int TS = HH_NMS_TILE, HS = TS + 4, PR = TS / 2 + 4;
     __shared__ float v[HS][HS + 1];
     __shared__ float rm[HS][TS + 1];
-    __shared__ u64 wbest[4];
+    __shared__ float patch[PR][PR + 1];  // half-res source rows/cols of this tile (mode 0)
+    __shared__ u64 wbest[2][4];
     const int tile = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
     const int ty = tile / tiles_x, tx = tile % tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < HS * HS; i += 256) {
-        const int ly = i / HS, lx = i % HS;
-        const int Y = y0 - 2 + ly, X = x0 - 2 + lx;
-        v[ly][lx] = (Y >= 0 && Y < src.H && X >= 0 && X < src.W) ? heat_at(src, b, k, Y, X) : -INFINITY;
+    if (src.mode == 0) {
+        // stage the half-res neighbourhood once (coalesced), then every full-res value of the tile is the
+        // same bilinear expression as heat_at(), evaluated from LDS
+        const int hh = src.H >> 1, wh = src.W >> 1;
+        const int py0 = src_index(hh, src.scale_h2, max(y0 - 2, 0)).i0, px0 = src_index(wh, src.scale_w2, max(x0 - 2, 0)).i0;
+        const float *img = src.avg + ((size_t)b * src.K + k) * hh * wh;
+        for (int i = tid; i < PR * PR; i += 256) {
+            const int r = i / PR, c = i % PR;
+            patch[r][c] = img[(size_t)min(py0 + r, hh - 1) * wh + min(px0 + c, wh - 1)];
+        }
+        __syncthreads();
+        for (int i = tid; i < HS * HS; i += 256) {
+            const int ly = i / HS, lx = i % HS;
+            const int Y = y0 - 2 + ly, X = x0 - 2 + lx;
+            float val = -INFINITY;
+            if (Y >= 0 && Y < src.H && X >= 0 && X < src.W) {
+                const Lin a = src_index(hh, src.scale_h2, Y), c = src_index(wh, src.scale_w2, X);
+                const float *r0 = patch[a.i0 - py0], *r1 = patch[a.i1 - py0];
+                const float t0 = __builtin_fmaf(r0[c.i0 - px0], c.w0, r0[c.i1 - px0] * c.w1);
+                const float t1 = __builtin_fmaf(r1[c.i0 - px0], c.w0, r1[c.i1 - px0] * c.w1);
+                val = __builtin_fmaf(t0, a.w0, t1 * a.w1);
+            }
+            v[ly][lx] = val;
+        }
+    } else {
+        for (int i = tid; i < HS * HS; i += 256) {
+            const int ly = i / HS, lx = i % HS;
+            const int Y = y0 - 2 + ly, X = x0 - 2 + lx;
+            v[ly][lx] = (Y >= 0 && Y < src.H && X >= 0 && X < src.W) ? heat_at(src, b, k, Y, X) : -INFINITY;
+        }
     }
     __syncthreads();
+    if (src.mode == 0) {  // exact maximum of every 4x4 full-res cell: the refine kernel prunes with it
+        const int cy = tid / (TS / 4), cx = tid % (TS / 4);
+        const int Y = y0 + 4 * cy, X = x0 + 4 * cx;
+        if (Y < src.H && X < src.W) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m = fmaxf(m, v[2 + 4 * cy + a][2 + 4 * cx + c]);
+            cellmax[(((size_t)b * src.K + k) * (src.H >> 2) + (Y >> 2)) * (src.W >> 2) + (X >> 2)] = m;
+        }
+    }
     for (int i = tid; i < HS * TS; i += 256) {
         const int ly = i / TS, lx = i % TS;
         float m = v[ly][lx];
@@ -139,31 +178,86 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
         keys[j] = (Y < src.H && X < src.W) ? make_key(vals[j], (unsigned)(Y * src.W + X)) : 0ull;
     }
     const size_t obase = ((((size_t)b * src.K + k) * gridDim.x) + tile) * M;
-    for (int r = 0; r < M; ++r) {
+    // The tile's ordering is: positive peaks (value desc), then zero-valued pixels (index asc), then negative
+    // peaks.  Fast path: positives are compacted and ranked in LDS, zeros are taken row by row with ballots;
+    // the generic M-round arg-max below only runs for what is left (negative peaks) or on list overflow.
+    __shared__ u64 clist[256];
+    __shared__ int ccount, nfilled;
+    float (*nv)[TS + 1] = rm;  // reuse: NMS'ed values of the tile
+    __syncthreads();           // everyone is done reading rm
+    if (tid == 0) { ccount = 0; nfilled = 0; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int p = tid + 256 * j;
+        nv[p / TS][p % TS] = keys[j] ? vals[j] : __builtin_nanf("");  // NaN = outside the image
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (keys[j] && vals[j] > 0.f) {
+            const int pos = atomicAdd(&ccount, 1);
+            if (pos < 256) clist[pos] = keys[j];
+        }
+    __syncthreads();
+    const int npos = ccount;
+    int start = 0;          // first output slot the generic rounds must fill
+    bool generic_all = npos > 256;
+    if (!generic_all) {
+        if (tid < npos) {
+            const u64 me = clist[tid];
+            int rank = 0;
+            for (int i = 0; i < npos; ++i) rank += clist[i] > me;
+            if (rank < M) {
+                cand_key[obase + rank] = me;
+                cand_val[obase + rank] = __uint_as_float((unsigned)(me >> 32) & 0x7fffffffu);
+            }
+        }
+        start = npos < M ? npos : M;
+        if (start < M && tid < 64) {  // zero-valued pixels in index order, one tile row per ballot
+            int filled = start;
+            for (int py = 0; py < TS && filled < M; ++py) {
+                const float z = nv[py][tid];
+                const bool is0 = (z == 0.f);
+                const u64 mask = __ballot(is0);
+                const int mypos = __popcll(mask & ((1ull << tid) - 1ull));
+                if (is0 && filled + mypos < M) {
+                    cand_key[obase + filled + mypos] = make_key(z, (unsigned)((y0 + py) * src.W + x0 + tid));
+                    cand_val[obase + filled + mypos] = z;
+                }
+                filled += __popcll(mask);
+            }
+            if (tid == 0) nfilled = filled < M ? filled : M;
+        } else if (tid == 0) nfilled = start;
+        __syncthreads();
+        start = nfilled;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (!(vals[j] < 0.f)) keys[j] = 0ull;  // only negative peaks are left for the generic rounds
+    }
+    for (int r = start; r < M; ++r) {
         u64 best = keys[0];
 #pragma unroll
         for (int j = 1; j < 16; ++j) best = keys[j] > best ? keys[j] : best;
         const u64 wb = wave_max_u64(best);
-        if ((tid & 63) == 0) wbest[tid >> 6] = wb;
-        __syncthreads();
-        u64 g = wbest[0];
+        if ((tid & 63) == 0) wbest[r & 1][tid >> 6] = wb;
+        __syncthreads();  // one barrier per round: the exchange buffer alternates
+        u64 g = wbest[r & 1][0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) g = wbest[w] > g ? wbest[w] : g;
+        for (int w = 1; w < 4; ++w) g = wbest[r & 1][w] > g ? wbest[r & 1][w] : g;
         if (g != 0ull && best == g) {  // keys are unique: exactly one owner
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 if (keys[j] == g) { cand_val[obase + r] = vals[j]; keys[j] = 0ull; }
         }
         if (tid == 0) cand_key[obase + r] = g;
-        __syncthreads();
     }
 }
 
-hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, u64 *cand_key, float *cand_val, hipStream_t s)
+hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, u64 *cand_key, float *cand_val, float *cellmax, hipStream_t s)
 {
     const int tiles_x = (src.W + HH_NMS_TILE - 1) / HH_NMS_TILE, tiles_y = (src.H + HH_NMS_TILE - 1) / HH_NMS_TILE;
     hipLaunchKernelGGL(nms_tile_topk_kernel, dim3(tiles_x * tiles_y, src.K, src.B), dim3(256), 0, s, src, M, tiles_x, cand_key,
-                       cand_val);
+                       cand_val, cellmax);
     return hipGetLastError();
 }
 
@@ -542,7 +636,8 @@ hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, float *
 // ------------------------------------------------------------------ refine
 // grouping.py:193-250.  (1) per person: mean tag of its detected joints.
 __global__ __launch_bounds__(64) void refine_mean_kernel(const DecodeSrc src, int M, const float *__restrict__ joints,
-                                                         const int32_t *__restrict__ num_people, float *__restrict__ ws_prev)
+                                                         const int32_t *__restrict__ num_people, float *__restrict__ ws_prev,
+                                                         int32_t *__restrict__ ws_jobs)
 {
     const int b = blockIdx.x, p = threadIdx.x, K = src.K, E = src.E, D = 3 + E;
     if (p >= num_people[b] || p >= M) return;
@@ -557,59 +652,207 @@ __global__ __launch_bounds__(64) void refine_mean_kernel(const DecodeSrc src, in
         }
     float *out = ws_prev + ((size_t)b * M + p) * (HH_MAX_EMB + 1);
     out[HH_MAX_EMB] = (float)nt;
-    if (nt) np_mean_rows(tl, nt, E, out);
+    if (!nt) return;
+    np_mean_rows(tl, nt, E, out);
+    for (int k = 0; k < K; ++k)  // work list for the arg-max kernel: every joint of this person still missing
+        if (J[k * D + 2] == 0.f) ws_jobs[1 + atomicAdd(ws_jobs, 1)] = (b << 16) | (p << 8) | k;
+}
+
+// (1b) per (b,k) quarter-res cell: [lo, hi] of the 3x3 tag taps (slack included) -- shared by every person
+__global__ __launch_bounds__(256) void tag_bounds_kernel(const DecodeSrc src, float *__restrict__ tagb)
+{
+    const int hq = src.H >> 2, wq = src.W >> 2, E = src.E;
+    const int k = blockIdx.y, b = blockIdx.z;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < hq * wq; c += gridDim.x * 256) {
+        const int qy = c / wq, qx = c % wq;
+        const int ya = max(qy - 1, 0), yb = min(qy + 1, hq - 1), xa = max(qx - 1, 0), xb = min(qx + 1, wq - 1);
+        for (int e = 0; e < E; ++e) {
+            const float *tq = src.tags_q[e] + (size_t)b * src.tags_bs[e] + (size_t)k * hq * wq;
+            float lo = INFINITY, hi = -INFINITY;
+            for (int y = ya; y <= yb; ++y)
+                for (int x = xa; x <= xb; ++x) {
+                    const float t = tq[(size_t)y * wq + x];
+                    lo = fminf(lo, t); hi = fmaxf(hi, t);
+                }
+            const float slack = 1e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-30f;  // >> 3 roundings of a convex combination
+            float *o = tagb + ((((size_t)b * src.K + k) * hq * wq + c) * E + e) * 2;
+            o[0] = lo - slack; o[1] = hi + slack;
+        }
+    }
 }
 
 // (2) per (person, joint) with score == 0: argmax over the full map of hm - round(||tag - mean||)
-__global__ __launch_bounds__(256) void refine_argmax_kernel(const DecodeSrc src, int M, float *__restrict__ joints,
-                                                            const int32_t *__restrict__ num_people,
-                                                            const float *__restrict__ ws_prev)
+// (first index among equal values, as np.argmax).  Exact branch-and-bound over 4x4-pixel cells:
+//   ub(cell) = max_hm(cell) - rint(lower bound of the tag distance over the cell) >= every value in the cell,
+//   where max_hm is the exact cell maximum written by the NMS kernel and the distance bound comes from the
+//   min/max of the 3x3 quarter-res tag taps every pixel of the cell interpolates (+ rounding slack).
+// Each thread evaluates its most promising cell exactly, the workgroup maximum of those is a valid lower
+// bound, and only cells with ub >= that bound are evaluated (typically a handful out of H*W/16).
+__global__ __launch_bounds__(256) void refine_argmax_kernel(const DecodeSrc src, int M, const int32_t *__restrict__ ws_jobs,
+                                                            const float *__restrict__ ws_prev, const float *__restrict__ cellmax,
+                                                            const float *__restrict__ tagb, u64 *__restrict__ ws_best)
 {
     __shared__ u64 wbest[4];
-    const int k = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, E = src.E, D = 3 + E;
-    if (p >= num_people[b]) return;
-    float *j = joints + (((size_t)b * M + p) * src.K + k) * D;
-    if (!(j[2] == 0.f)) return;
-    const float *prev = ws_prev + ((size_t)b * M + p) * (HH_MAX_EMB + 1);
-    if (prev[HH_MAX_EMB] == 0.f) return;
-    float mean[HH_MAX_EMB];
-    for (int e = 0; e < E; ++e) mean[e] = prev[e];
-    const int HW = src.H * src.W;
-    u64 best = 0ull;
-    for (int i = tid; i < HW; i += 256) {
-        const int y = i / src.W, x = i % src.W;
-        float s = 0.f;
-        for (int e = 0; e < E; ++e) {
-            float d = tag_at(src, b, k, y, x, e) - mean[e];
-            d = d * d;
-            s = e ? s + d : d;
+    const int tid = threadIdx.x, E = src.E;
+    const int njobs = ws_jobs[0];
+    for (int job = blockIdx.x; job < njobs; job += gridDim.x) {  // persistent grid over the missing joints
+        const int code = ws_jobs[1 + job];
+        const int b = code >> 16, p = (code >> 8) & 0xff, k = code & 0xff;
+        const float *prev = ws_prev + ((size_t)b * M + p) * (HH_MAX_EMB + 1);
+        float mean[HH_MAX_EMB];
+        for (int e = 0; e < E; ++e) mean[e] = prev[e];
+        u64 best = 0ull;
+        auto pixel = [&](int y, int x) {  // generic path: the same expressions as heat_at / tag_at
+            float s = 0.f;
+            for (int e = 0; e < E; ++e) {
+                float d = tag_at(src, b, k, y, x, e) - mean[e];
+                d = d * d;
+                s = e ? s + d : d;
+            }
+            const float v = heat_at(src, b, k, y, x) - rintf(__fsqrt_rn(s));
+            const u64 key = make_key(v, (unsigned)(y * src.W + x));
+            best = key > best ? key : best;
+        };
+        if (src.mode == 1) {
+            for (int x = tid; x < src.W; x += 256)
+                for (int y = 0; y < src.H; ++y) pixel(y, x);
+        } else {
+            const int hq = src.H >> 2, wq = src.W >> 2, wh = src.W >> 1;
+            const float *avg = src.avg + ((size_t)b * src.K + k) * (size_t)(src.H >> 1) * wh;
+            const float *cmax = cellmax + ((size_t)b * src.K + k) * hq * wq;
+            constexpr int TO[4] = {0, 0, 1, 1};  // tag source row offset (from q-1) of sub-pixel j, x4 upsampling
+            constexpr float TW1[4] = {0.625f, 0.875f, 0.125f, 0.375f};
+            constexpr int HO[4] = {0, 1, 1, 2};  // heat source row offset (from 2q-1), x2 upsampling
+            constexpr float HW1[4] = {0.75f, 0.25f, 0.75f, 0.25f};
+            // exact evaluation of the 16 pixels of one cell.  Interior: the bilinear source rows/cols and
+            // weights are fixed, exactly representable patterns, taps are loaded once and the horizontal
+            // interpolations shared -- per pixel the arithmetic is bilerp()'s, bit for bit.
+            auto eval_cell = [&](int qy, int qx) {
+                if (qy == 0 || qx == 0 || qy == hq - 1 || qx == wq - 1) {  // clamped borders
+                    for (int jy = 0; jy < 4; ++jy)
+                        for (int jx = 0; jx < 4; ++jx) pixel(4 * qy + jy, 4 * qx + jx);
+                    return;
+                }
+                float hrow[4][4];
+                const float *a0 = avg + (size_t)(2 * qy - 1) * wh + 2 * qx - 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t[4] = {a0[r * wh], a0[r * wh + 1], a0[r * wh + 2], a0[r * wh + 3]};
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx)
+                        hrow[r][jx] = __builtin_fmaf(t[HO[jx]], 1.f - HW1[jx], t[HO[jx] + 1] * HW1[jx]);
+                }
+                float dist2[16];
+#pragma unroll
+                for (int e = 0; e < HH_MAX_EMB; ++e) {
+                    if (e >= E) break;
+                    const float *t0 = src.tags_q[e] + (size_t)b * src.tags_bs[e] + (size_t)k * hq * wq + (size_t)(qy - 1) * wq + qx - 1;
+                    float trow[3][4];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float t[3] = {t0[r * wq], t0[r * wq + 1], t0[r * wq + 2]};
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx)
+                            trow[r][jx] = __builtin_fmaf(t[TO[jx]], 1.f - TW1[jx], t[TO[jx] + 1] * TW1[jx]);
+                    }
+#pragma unroll
+                    for (int jy = 0; jy < 4; ++jy)
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx) {
+                            const float tg = __builtin_fmaf(trow[TO[jy]][jx], 1.f - TW1[jy], trow[TO[jy] + 1][jx] * TW1[jy]);
+                            float d = tg - mean[e];
+                            d = d * d;
+                            dist2[jy * 4 + jx] = e ? dist2[jy * 4 + jx] + d : d;
+                        }
+                }
+#pragma unroll
+                for (int jy = 0; jy < 4; ++jy)
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        const float hv = __builtin_fmaf(hrow[HO[jy]][jx], 1.f - HW1[jy], hrow[HO[jy] + 1][jx] * HW1[jy]);
+                        const float v = hv - rintf(__fsqrt_rn(dist2[jy * 4 + jx]));
+                        const u64 key = make_key(v, (unsigned)((4 * qy + jy) * src.W + 4 * qx + jx));
+                        best = key > best ? key : best;
+                    }
+            };
+            // upper bound of a cell
+            const float *tb = tagb + ((size_t)b * src.K + k) * hq * wq * E * 2;
+            auto cell_ub = [&](int c) -> float {
+                float lb2 = 0.f;
+                for (int e = 0; e < E; ++e) {
+                    const float2 lh = *reinterpret_cast<const float2 *>(tb + ((size_t)c * E + e) * 2);
+                    const float d = fmaxf(fmaxf(mean[e] - lh.y, lh.x - mean[e]), 0.f);
+                    lb2 += d * d;
+                }
+                const float lb = __fsqrt_rn(lb2) * (1.f - 2e-6f);  // below the reference's own rounded distance
+                return cmax[c] - rintf(lb);
+            };
+            const int ncells = hq * wq;
+            float my_ub = -INFINITY;
+            int my_cell = -1;
+            for (int c = tid; c < ncells; c += 256) {
+                const float ub = cell_ub(c);
+                if (ub > my_ub) { my_ub = ub; my_cell = c; }
+            }
+            if (my_cell >= 0) eval_cell(my_cell / wq, my_cell % wq);
+            // workgroup-wide lower bound = best exactly evaluated value so far
+            u64 wb = wave_max_u64(best);
+            if ((tid & 63) == 0) wbest[tid >> 6] = wb;
+            __syncthreads();
+            u64 g = wbest[0];
+            for (int w = 1; w < 4; ++w) g = wbest[w] > g ? wbest[w] : g;
+            __syncthreads();
+            unsigned gb = (unsigned)(g >> 32);  // invert make_key's order-preserving map
+            gb = (gb & 0x80000000u) ? (gb & 0x7fffffffu) : ~gb;
+            const float bound = __uint_as_float(gb);
+            for (int c = tid; c < ncells; c += 256) {
+                if (c == my_cell) continue;
+                if (cell_ub(c) >= bound) eval_cell(c / wq, c % wq);
+            }
         }
-        const float v = heat_at(src, b, k, y, x) - rintf(__fsqrt_rn(s));
-        const u64 key = make_key(v, (unsigned)i);
-        best = key > best ? key : best;
-    }
-    const u64 wb = wave_max_u64(best);
-    if ((tid & 63) == 0) wbest[tid >> 6] = wb;
-    __syncthreads();
-    if (tid == 0) {
-        u64 g = wbest[0];
-        for (int w = 1; w < 4; ++w) g = wbest[w] > g ? wbest[w] : g;
-        const unsigned idx = 0xffffffffu - (unsigned)(g & 0xffffffffull);
-        const int y = (int)(idx / (unsigned)src.W), x = (int)(idx % (unsigned)src.W);
-        const float val = heat_at(src, b, k, y, x);
-        if (val > 0.f) {
-            double fx = (double)x + 0.5, fy = (double)y + 0.5;
-            const int xr = min(x + 1, src.W - 1), xl = max(x - 1, 0), yd = min(y + 1, src.H - 1), yu = max(y - 1, 0);
-            if (heat_at(src, b, k, y, xr) > heat_at(src, b, k, y, xl)) fx += 0.25; else fx -= 0.25;
-            if (heat_at(src, b, k, yd, x) > heat_at(src, b, k, yu, x)) fy += 0.25; else fy -= 0.25;
-            j[0] = (float)fx; j[1] = (float)fy; j[2] = val;
+        const u64 wb2 = wave_max_u64(best);
+        if ((tid & 63) == 0) wbest[tid >> 6] = wb2;
+        __syncthreads();
+        if (tid == 0) {
+            u64 g = wbest[0];
+            for (int w = 1; w < 4; ++w) g = wbest[w] > g ? wbest[w] : g;
+            ws_best[((size_t)b * M + p) * src.K + k] = g;
         }
+        __syncthreads();
     }
 }
 
-hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev, hipStream_t s)
+__global__ __launch_bounds__(64) void refine_apply_kernel(const DecodeSrc src, int M, float *__restrict__ joints,
+                                                          const int32_t *__restrict__ num_people, const u64 *__restrict__ ws_best)
 {
-    hipLaunchKernelGGL(refine_mean_kernel, dim3(src.B), dim3(64), 0, s, src, M, joints, num_people, ws_prev);
-    hipLaunchKernelGGL(refine_argmax_kernel, dim3(src.K, M, src.B), dim3(256), 0, s, src, M, joints, num_people, ws_prev);
+    const int p = blockIdx.x, b = blockIdx.y, k = threadIdx.x, D = 3 + src.E;
+    if (p >= num_people[b] || k >= src.K) return;
+    const u64 g = ws_best[((size_t)b * M + p) * src.K + k];
+    if (g == 0ull) return;  // joint was present (or the person has no tag): nothing scanned
+    float *j = joints + (((size_t)b * M + p) * src.K + k) * D;
+    const unsigned idx = 0xffffffffu - (unsigned)(g & 0xffffffffull);
+    const int y = (int)(idx / (unsigned)src.W), x = (int)(idx % (unsigned)src.W);
+    const float val = heat_at(src, b, k, y, x);
+    if (val > 0.f) {
+        double fx = (double)x + 0.5, fy = (double)y + 0.5;
+        const int xr = min(x + 1, src.W - 1), xl = max(x - 1, 0), yd = min(y + 1, src.H - 1), yu = max(y - 1, 0);
+        if (heat_at(src, b, k, y, xr) > heat_at(src, b, k, y, xl)) fx += 0.25; else fx -= 0.25;
+        if (heat_at(src, b, k, yd, x) > heat_at(src, b, k, yu, x)) fy += 0.25; else fy -= 0.25;
+        j[0] = (float)fx; j[1] = (float)fy; j[2] = val;
+    }
+}
+
+hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev,
+                         unsigned long long *ws_best, int32_t *ws_jobs, const float *cellmax, float *tagb, hipStream_t s)
+{
+    if (src.mode == 0)
+        hipLaunchKernelGGL(tag_bounds_kernel, dim3(((src.H >> 2) * (src.W >> 2) + 255) / 256, src.K, src.B), dim3(256), 0, s, src, tagb);
+    hipError_t e = hipMemsetAsync(ws_best, 0, (size_t)src.B * M * src.K * sizeof(u64), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws_jobs, 0, 16, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(refine_mean_kernel, dim3(src.B), dim3(64), 0, s, src, M, joints, num_people, ws_prev, ws_jobs);
+    hipLaunchKernelGGL(refine_argmax_kernel, dim3(2048), dim3(256), 0, s, src, M, ws_jobs, ws_prev, cellmax, tagb, ws_best);
+    hipLaunchKernelGGL(refine_apply_kernel, dim3(M, src.B), dim3(64), 0, s, src, M, joints, num_people, ws_best);
     return hipGetLastError();
 }

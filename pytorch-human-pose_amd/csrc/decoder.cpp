@@ -11,9 +11,9 @@ struct hh_decoder {
     double det_thr, tag_thr;
     // reserved capacity
     int rB = 0, rH = 0, rW = 0, rE = 0;
-    float *avg = nullptr, *cand_val = nullptr, *tags_k = nullptr, *scores_k = nullptr, *ws_tags = nullptr, *ws_prev = nullptr;
-    unsigned long long *cand_key = nullptr;
-    int32_t *coords_k = nullptr, *status = nullptr;
+    float *avg = nullptr, *cellmax = nullptr, *tagb = nullptr, *cand_val = nullptr, *tags_k = nullptr, *scores_k = nullptr, *ws_tags = nullptr, *ws_prev = nullptr;
+    unsigned long long *cand_key = nullptr, *ws_best = nullptr;
+    int32_t *coords_k = nullptr, *status = nullptr, *ws_jobs = nullptr;
     std::vector<void *> allocs;
     int lastB = 0, lastE = 0;
     void release()
@@ -43,6 +43,8 @@ int hh_decoder::reserve(int B, int H, int W, int E)
     };
     const size_t nt = (size_t)ntiles_of(nH, nW);
     if (alloc((size_t)nB * K * (nH / 2) * (nW / 2) * 4, (void **)&avg)) return 1;
+    if (alloc((size_t)nB * K * (nH / 4 + 1) * (nW / 4 + 1) * 4, (void **)&cellmax)) return 1;
+    if (alloc((size_t)nB * K * (nH / 4 + 1) * (nW / 4 + 1) * nE * 2 * 4, (void **)&tagb)) return 1;
     if (alloc((size_t)nB * K * nt * M * 8, (void **)&cand_key)) return 1;
     if (alloc((size_t)nB * K * nt * M * 4, (void **)&cand_val)) return 1;
     if (alloc((size_t)nB * K * M * nE * 4, (void **)&tags_k)) return 1;
@@ -50,6 +52,8 @@ int hh_decoder::reserve(int B, int H, int W, int E)
     if (alloc((size_t)nB * K * M * 4, (void **)&scores_k)) return 1;
     if (alloc((size_t)nB * M * (K + 1) * nE * 4, (void **)&ws_tags)) return 1;
     if (alloc((size_t)nB * M * (HH_MAX_EMB + 1) * 4, (void **)&ws_prev)) return 1;
+    if (alloc((size_t)nB * M * K * 8, (void **)&ws_best)) return 1;
+    if (alloc(((size_t)nB * M * K + 4) * 4, (void **)&ws_jobs)) return 1;
     if (alloc(64, (void **)&status)) return 1;
     HH_CHECK_HIP(hipMemset(status, 0, 64));
     rB = nB; rH = nH; rW = nW; rE = nE;
@@ -59,12 +63,14 @@ int hh_decoder::reserve(int B, int H, int W, int E)
 int hh_decoder::run(DecodeSrc &src, int adjust, int refine, float *joints, float *scores, int32_t *num_people, hipStream_t s)
 {
     src.K = K;
+    src.scale_h2 = (float)(src.H / 2) / (float)src.H; src.scale_w2 = (float)(src.W / 2) / (float)src.W;
+    src.scale_h4 = (float)(src.H / 4) / (float)src.H; src.scale_w4 = (float)(src.W / 4) / (float)src.W;
     const int nt = ntiles_of(src.H, src.W);
-    HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, s));
+    HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, cellmax, s));
     HH_CHECK_HIP(launch_topk_merge(src, M, nt, cand_key, cand_val, tags_k, coords_k, scores_k, s));
     HH_CHECK_HIP(launch_match(tags_k, coords_k, scores_k, src.B, K, M, src.E, det_thr, tag_thr, joints, num_people, ws_tags, status, s));
     HH_CHECK_HIP(launch_adjust_scores(src, M, adjust, joints, num_people, scores, s));
-    if (refine) HH_CHECK_HIP(launch_refine(src, M, joints, num_people, ws_prev, s));
+    if (refine) HH_CHECK_HIP(launch_refine(src, M, joints, num_people, ws_prev, ws_best, ws_jobs, cellmax, tagb, s));
     lastB = src.B; lastE = src.E;
     return 0;
 }
