@@ -74,6 +74,13 @@ int hh_profile_count(const hh_net *net);
 int hh_profile_get(hh_net *net, int index, int *cfg, double *flops, float *ms, const char **layer);
 int hh_conv_config(int cfg, int out[7]);
 
+/* Kernel micro-benchmark used by tools/conv_bench.py (not on the hot path): `iters` back-to-back launches of
+ * convolution instantiation `cfg` on random bf16 data, HIP-event timed; returns ms per launch.        */
+int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, int cout, int with_res, int relu, int iters,
+                        float *ms_per_launch);
+
+int hh_debug_bb_bench(int B, int H, int W, int iters, float *ms_per_launch, unsigned long long *stamps64);
+
 /* Debug taps (parity tests): when enabled, hh_forward copies selected intermediate
  * activations; hh_tap_read converts one to fp32 NCHW on the host. Names follow the
  * reference module paths, e.g. "stages.2.blocks.3#1" = output 1 of backbone.stages[2].blocks[3]. */

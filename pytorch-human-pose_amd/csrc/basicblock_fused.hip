@@ -1,0 +1,315 @@
+// Fused BasicBlock for 32-channel branches (the highest-resolution HRNet branch and the
+// HigherHRNet deconv head):   out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x)
+// -- /root/reference/src/keypoints/architectures/hrnet.py:108-124 -- in ONE kernel.
+//
+// Why: at C=32 a 3x3 conv has 144 FLOP per activation byte; run layer by layer the block moves
+// x -> mid -> out through HBM (5 tensor passes, ~160 MB at 32x128x128x32) and is bandwidth/latency
+// bound.  Fused, the 18x34 intermediate tile lives in LDS as bf16 and only x (once, + halo) and
+// out cross HBM (2 passes).
+//
+// Shape of one workgroup (256 threads = 4 waves, one per SIMD; persistent over tiles):
+//   output tile 16x32 px, mid tile 18x34 px (flattened into 20 MFMA column tiles of 32 pixels: 5 per
+//   wave), input patch 20x36 px.  Both 3x3x32x32 weight sets stay in LDS for the life of the
+//   workgroup.  MFMA roles as in conv_mfma.hip: A = weights (32 couts x 16 cin), B = pixels.
+// Per tile (stamped with s_memtime in a -DHH_STAMP build, see tools/bb_bench.py):
+//   * the next tile's 57.6 KB patch is prefetched into registers ONE 16-byte load per conv1 k-step
+//     (a burst of 12 loads per thread back-pressures the CU's load path, ~10 B/cycle, and stalls the MFMAs)
+//   * LDS fragment reads run one k-step ahead of the MFMAs (sched_group_barrier pins the order)
+//   * the residual is two extra MFMAs per column tile with an identity A fragment (exact: x * 1.0 in fp32)
+//     instead of 16 LDS reads + 16 converts + 16 adds per lane
+//   * epilogues pair the two half-waves with v_permlane32_swap so every lane writes 16 contiguous bytes.
+#include "kernels.h"
+
+#include <utility>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ unsigned pack_relu_bf16x2(float a, float b)
+{
+    f32x2 f = {fmaxf(a, 0.f), fmaxf(b, 0.f)};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// 32 couts of one pixel: lanes (r,0) hold couts 8g..8g+3, lanes (r,1) couts 8g+4..8g+7 in acc[4g..4g+3].
+// Returns for m = 0,1 the 16 bytes (bf16, ReLU applied) of couts 16m+8h .. 16m+8h+7 of this lane's pixel.
+__device__ __forceinline__ void pack_rows16(const f32x16 &acc, bool zero, u32x4 out[2])
+{
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        unsigned x0 = pack_relu_bf16x2(acc[8 * m + 0], acc[8 * m + 1]), x1 = pack_relu_bf16x2(acc[8 * m + 2], acc[8 * m + 3]);
+        unsigned y0 = pack_relu_bf16x2(acc[8 * m + 4], acc[8 * m + 5]), y1 = pack_relu_bf16x2(acc[8 * m + 6], acc[8 * m + 7]);
+        // lanes 0-31: X = couts 16m..+3, Y = 16m+8..+11; lanes 32-63: X = 16m+4..+7, Y = 16m+12..+15.
+        // swap X[32..63] <-> Y[0..31]: lanes 0-31 end with (X,Y) = couts 16m..16m+7, lanes 32-63 with 16m+8..16m+15
+        auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+        out[m] = zero ? u32x4{0u, 0u, 0u, 0u} : u32x4{s0[0], s1[0], s0[1], s1[1]};
+    }
+}
+
+constexpr int TH = 16, TW = 32;          // output tile
+constexpr int MH = TH + 2, MW = TW + 2;  // conv1 output (= conv2 input) tile
+constexpr int IH = TH + 4, IW = TW + 4;  // input patch
+constexpr int PS = 80;                   // bytes per staged pixel: 32 bf16 + 16 pad (odd number of 16-B slots)
+constexpr int MPIX = MH * MW;            // 612 mid pixels -> 20 column tiles of 32 (28 idle lanes)
+constexpr int PATCH_BYTES = IH * IW * PS;           // 57600
+constexpr int MID_BYTES = 20 * 32 * PS;             // 51200
+constexpr int W_BYTES = 9 * 4 * 32 * 16;            // 18432 per conv
+constexpr int P_UNITS = IH * IW * 4;                // 2880 16-byte units
+constexpr int NPL = (P_UNITS + 255) / 256;          // 12
+constexpr int W_UNITS = W_BYTES / 16;               // 1152
+}  // namespace
+
+#ifdef HH_STAMP
+#define STAMP(i) do { if (p.stamps && blockIdx.x == 0 && tid == 0) { const int tile_ix_ = (t - (int)blockIdx.x) / (int)gridDim.x; if (tile_ix_ < 8) p.stamps[tile_ix_ * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define STAMP(i)
+#endif
+
+size_t bb_fused_lds_bytes() { return PATCH_BYTES + MID_BYTES + 2 * W_BYTES; }
+
+__global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *lds_p = smem;
+    char *lds_m = smem + PATCH_BYTES;
+    char *lds_w1 = lds_m + MID_BYTES;
+    char *lds_w2 = lds_w1 + W_BYTES;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- both weight sets: loaded once per workgroup
+    for (int u = tid; u < W_UNITS; u += 256) {
+        reinterpret_cast<u32x4 *>(lds_w1)[u] = reinterpret_cast<const u32x4 *>(p.w1)[u];
+        reinterpret_cast<u32x4 *>(lds_w2)[u] = reinterpret_cast<const u32x4 *>(p.w2)[u];
+    }
+    float4 b1v[4], b2v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        b1v[g] = *reinterpret_cast<const float4 *>(p.b1 + 8 * g + 4 * h);
+        b2v[g] = *reinterpret_cast<const float4 *>(p.b2 + 8 * g + 4 * h);
+    }
+    // identity A fragments (rows = couts, k = cin): frag kk has A[r][k] = 1 where 16*kk + k == r
+    u32x4 ident[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int j = r - 16 * kk - 8 * h;  // element index inside this lane's 8-wide k slice
+        const unsigned one = (j & 1) ? 0x3f800000u : 0x00003f80u;  // bf16 1.0 in the high / low half of a dword
+        const bool on = j >= 0 && j < 8;
+        ident[kk] = u32x4{on && (j >> 1) == 0 ? one : 0u, on && (j >> 1) == 1 ? one : 0u, on && (j >> 1) == 2 ? one : 0u,
+                          on && (j >> 1) == 3 ? one : 0u};
+    }
+
+    // ---- tile-invariant per-thread geometry
+    int pl_off[NPL], pl_yx[NPL];  // prefetch unit i: element offset from the tile's patch origin, (py << 8) | px
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int u = tid + 256 * i, pix = u >> 2, py = pix / IW, px = pix % IW;
+        pl_off[i] = (py * p.W + px) * p.in_cs + (u & 3) * 8;
+        pl_yx[i] = u < P_UNITS ? ((py << 8) | px) : (255 << 8);  // py = 255 -> never inside
+    }
+    int paddr[5], maddr[5], myx[5];  // conv1 column tiles of this wave: patch read base, mid write base, (my << 8) | mx
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int pidx = (wave * 5 + q) * 32 + r;
+        const int pc = pidx < MPIX ? pidx : MPIX - 1;  // idle lanes read a valid pixel, never write
+        const int my = pc / MW, mx = pc % MW;
+        paddr[q] = (my * IW + mx) * PS + h * 16;
+        maddr[q] = pidx < MPIX ? pidx * PS + h * 16 : -1;
+        myx[q] = (my << 8) | mx;
+    }
+
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    u32x4 preg[NPL];
+    unsigned pf_mask = 0;            // bit i: prefetched unit i lies inside the image (else it is conv padding = 0)
+    const bf16_raw *pf_base = p.in;  // patch origin of the tile being prefetched
+    int pf_iy0 = 0, pf_ix0 = 0;
+    auto pf_setup = [&](int t) {
+        const int b = t / tiles_per_img, tt = t % tiles_per_img;
+        pf_iy0 = (tt / p.tiles_x) * TH - 2; pf_ix0 = (tt % p.tiles_x) * TW - 2;
+        pf_base = p.in + ((ptrdiff_t)b * p.H * p.W + (ptrdiff_t)pf_iy0 * p.W + pf_ix0) * p.in_cs;
+        pf_mask = 0;
+    };
+    auto pf_load = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int iy = pf_iy0 + (pl_yx[i] >> 8), ix = pf_ix0 + (pl_yx[i] & 255);
+        const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        // the load result is not touched here (no s_waitcnt inside the MFMA loop); padding is applied in write_patch
+        preg[i] = *reinterpret_cast<const u32x4 *>(ok ? pf_base + pl_off[i] : p.in);
+        pf_mask |= ok ? (1u << i) : 0u;
+    };
+    auto write_patch = [&]() {
+        static_for<NPL>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int u = tid + 256 * i;
+            if (u < P_UNITS)
+                *reinterpret_cast<u32x4 *>(lds_p + (u >> 2) * PS + (u & 3) * 16) =
+                    (pf_mask >> i) & 1u ? preg[i] : u32x4{0u, 0u, 0u, 0u};  // zero outside the image = conv1 padding
+        });
+    };
+
+    int t = blockIdx.x;
+    if (t < p.ntiles) {
+        pf_setup(t);
+        static_for<NPL>(pf_load);
+    }
+    write_patch();
+    __syncthreads();
+
+    for (; t < p.ntiles; t += gridDim.x) {
+        const int b = t / tiles_per_img, tt = t % tiles_per_img;
+        const int oy0 = (tt / p.tiles_x) * TH, ox0 = (tt % p.tiles_x) * TW;
+        const int tn = t + gridDim.x;
+        const bool more = tn < p.ntiles;
+        if (more) pf_setup(tn);
+        STAMP(0);
+
+        // ================= conv1 + bn1 + relu -> mid tile (LDS, bf16) =================
+        {
+            f32x16 acc[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[q][4 * g + 0] = b1v[g].x; acc[q][4 * g + 1] = b1v[g].y;
+                    acc[q][4 * g + 2] = b1v[g].z; acc[q][4 * g + 3] = b1v[g].w;
+                }
+            u32x4 fa[2], fb[2][5];
+            auto ld1 = [&](int st, int buf) {
+                const int tap = st >> 1, kk = st & 1, ky = tap / 3, kx = tap % 3;
+                fa[buf] = *reinterpret_cast<const u32x4 *>(lds_w1 + ((tap * 4 + kk * 2 + h) * 32 + r) * 16);
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    fb[buf][q] = *reinterpret_cast<const u32x4 *>(lds_p + paddr[q] + (ky * IW + kx) * PS + kk * 32);
+            };
+            ld1(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            static_for<18>([&](auto ic) {
+                constexpr int st = decltype(ic)::value;
+                if (st + 1 < 18) {
+                    ld1(st + 1, (st + 1) & 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                }
+                if constexpr (st < NPL) {  // one prefetch load per k-step
+                    if (more) pf_load(ic);
+                }
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st & 1]),
+                                                                     __builtin_bit_cast(bf16x8, fb[st & 1][q]), acc[q], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 5, 0);
+            });
+            STAMP(1);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int gy = oy0 - 1 + (myx[q] >> 8), gx = ox0 - 1 + (myx[q] & 255);
+                // conv2 zero-pads the *feature map*: mid pixels outside the image are 0, not conv1(padding)
+                const bool outside = gy < 0 || gy >= p.H || gx < 0 || gx >= p.W;
+                u32x4 o[2];
+                pack_rows16(acc[q], outside, o);
+                if (maddr[q] >= 0) {
+                    *reinterpret_cast<u32x4 *>(lds_m + maddr[q]) = o[0];
+                    *reinterpret_cast<u32x4 *>(lds_m + maddr[q] + 32) = o[1];
+                }
+            }
+        }
+        __syncthreads();
+        STAMP(2);
+
+        // ================= conv2 + bn2 + residual + relu =================
+        f32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[q][4 * g + 0] = b2v[g].x; acc[q][4 * g + 1] = b2v[g].y;
+                acc[q][4 * g + 2] = b2v[g].z; acc[q][4 * g + 3] = b2v[g].w;
+            }
+        {
+            u32x4 fa[2], fb[2][4];
+            auto ld2 = [&](int st, int buf) {
+                if (st < 18) {
+                    const int tap = st >> 1, kk = st & 1, ky = tap / 3, kx = tap % 3;
+                    fa[buf] = *reinterpret_cast<const u32x4 *>(lds_w2 + ((tap * 4 + kk * 2 + h) * 32 + r) * 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        fb[buf][q] = *reinterpret_cast<const u32x4 *>(lds_m + ((wave * 4 + q + ky) * MW + r + kx) * PS + kk * 32 + h * 16);
+                } else {  // steps 18,19: residual = identity x centre of the input patch
+                    const int kk = st - 18;
+                    fa[buf] = ident[kk];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        fb[buf][q] = *reinterpret_cast<const u32x4 *>(lds_p + ((wave * 4 + q + 2) * IW + r + 2) * PS + kk * 32 + h * 16);
+                }
+            };
+            ld2(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+            static_for<20>([&](auto ic) {
+                constexpr int st = decltype(ic)::value;
+                if (st + 1 < 20) {
+                    ld2(st + 1, (st + 1) & 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, st + 1 < 18 ? 5 : 4, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st & 1]),
+                                                                     __builtin_bit_cast(bf16x8, fb[st & 1][q]), acc[q], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+            });
+        }
+        STAMP(3);
+        __syncthreads();  // every wave is done with the mid tile and the patch
+        STAMP(4);
+        if (more) write_patch();
+        // ---- epilogue: ReLU, bf16, 16 contiguous bytes per lane straight to HBM
+        bf16_raw *out_b = p.out + (size_t)b * p.H * p.W * p.out_cs;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oy = oy0 + wave * 4 + q, ox = ox0 + r;
+            u32x4 o[2];
+            pack_rows16(acc[q], false, o);
+            if (oy < p.H && ox < p.W) {
+                bf16_raw *dst = out_b + ((size_t)oy * p.W + ox) * p.out_cs + 8 * h;
+                *reinterpret_cast<u32x4 *>(dst) = o[0];
+                *reinterpret_cast<u32x4 *>(dst + 16) = o[1];
+            }
+        }
+        STAMP(5);
+        __syncthreads();  // next patch visible
+        STAMP(6);
+        STAMP(7);
+    }
+}
+
+hipError_t bb_fused_init()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(bb_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bb_fused_lds_bytes());
+}
+
+hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s)
+{
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    const int grid = p.ntiles < num_cus ? p.ntiles : num_cus;
+    hipLaunchKernelGGL(bb_fused_kernel, dim3(grid), dim3(256), bb_fused_lds_bytes(), s, p);
+    return hipGetLastError();
+}

@@ -1,5 +1,6 @@
 // extern "C" surface declared in include/hhrnet.h (network part).
 #include <cstring>
+#include <vector>
 
 #include "../../include/hhrnet.h"
 #include "engine.h"
@@ -126,3 +127,107 @@ int hh_transform_coords(const float *xy_in, int n, double cx, double cy, double 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// Kernel micro-benchmark (tools/conv_bench.py): one convolution shape, random bf16 data, `iters` back-to-back
+// launches of instantiation `cfg` timed with HIP events on `stream`.  Not part of the hot path.
+extern "C" int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, int cout, int with_res, int relu, int iters,
+                                   float *ms_per_launch)
+{
+    if (cfg < 0 || cfg >= conv_num_configs()) { hh_set_error("bad cfg"); return 1; }
+    HH_CHECK_HIP(conv_init());
+    const ConvConfig &c = conv_config(cfg);
+    if (cin % c.KC) { hh_set_error("cin must be a multiple of the config's KC"); return 1; }
+    const int coutp = (cout + c.cout_t() - 1) / c.cout_t() * c.cout_t();
+    const int Ho = c.S == 2 ? Hin / 2 : Hin, Wo = c.S == 2 ? Win / 2 : Win;
+    const size_t n_in = (size_t)B * Hin * Win * cin, n_out = (size_t)B * Ho * Wo * coutp;
+    const size_t n_w = (size_t)coutp * cin * c.KS * c.KS;
+    std::vector<bf16_raw> h_in(n_in), h_w(n_w);
+    uint32_t s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (bf16_raw)(0x3c00u + ((s >> 16) & 0x1ffu) + ((s >> 30) << 15)); };
+    for (auto &v : h_in) v = rnd();
+    for (auto &v : h_w) v = rnd();
+    bf16_raw *d_in, *d_out, *d_res, *d_w;
+    float *d_bias;
+    HH_CHECK_HIP(hipMalloc((void **)&d_in, n_in * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_out, n_out * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_res, n_out * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_w, n_w * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_bias, (size_t)coutp * 4));
+    HH_CHECK_HIP(hipMemcpy(d_in, h_in.data(), n_in * 2, hipMemcpyHostToDevice));
+    HH_CHECK_HIP(hipMemcpy(d_w, h_w.data(), n_w * 2, hipMemcpyHostToDevice));
+    HH_CHECK_HIP(hipMemset(d_res, 0, n_out * 2));
+    HH_CHECK_HIP(hipMemset(d_bias, 0, (size_t)coutp * 4));
+    ConvParams p{};
+    p.in = d_in; p.in_cs = cin; p.Hin = Hin; p.Win = Win; p.w = d_w; p.bias = d_bias;
+    p.res = with_res ? d_res : nullptr; p.res_cs = coutp;
+    p.out = d_out; p.out_cs = coutp; p.Hob = Ho; p.Wob = Wo; p.osy = p.osx = 1;
+    p.Ho = Ho; p.Wo = Wo; p.cin = cin; p.cout_real = cout; p.cout_store = coutp; p.relu = relu;
+    p.pad_y = p.pad_x = (c.KS - 1) / 2; p.B = B;
+    p.tiles_x = (Wo + c.TW - 1) / c.TW; p.tiles_y = (Ho + c.th() - 1) / c.th(); p.ncg = coutp / c.cout_t();
+    hipStream_t st;
+    HH_CHECK_HIP(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    HH_CHECK_HIP(hipEventCreate(&e0));
+    HH_CHECK_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) HH_CHECK_HIP(conv_launch(cfg, p, st));
+    HH_CHECK_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) HH_CHECK_HIP(conv_launch(cfg, p, st));
+    HH_CHECK_HIP(hipEventRecord(e1, st));
+    HH_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    HH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(st);
+    hipFree(d_in); hipFree(d_out); hipFree(d_res); hipFree(d_w); hipFree(d_bias);
+    return 0;
+}
+
+// Fused BasicBlock micro-benchmark; with a -DHH_STAMP build also returns s_memtime stamps of workgroup 0.
+extern "C" int hh_debug_bb_bench(int B, int H, int W, int iters, float *ms_per_launch, unsigned long long *stamps64)
+{
+    HH_CHECK_HIP(conv_init());
+    HH_CHECK_HIP(bb_fused_init());
+    const size_t n = (size_t)B * H * W * 32;
+    std::vector<bf16_raw> h_in(n), h_w(9 * 32 * 32);
+    uint32_t s = 777u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (bf16_raw)(0x3c00u + ((s >> 16) & 0x1ffu) + ((s >> 30) << 15)); };
+    for (auto &v : h_in) v = rnd();
+    for (auto &v : h_w) v = (bf16_raw)(rnd() - 0x0400u);
+    bf16_raw *d_in, *d_out, *d_w;
+    float *d_b;
+    unsigned long long *d_st;
+    HH_CHECK_HIP(hipMalloc((void **)&d_in, n * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_out, n * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_w, h_w.size() * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_b, 32 * 4));
+    HH_CHECK_HIP(hipMalloc((void **)&d_st, 64 * 8));
+    HH_CHECK_HIP(hipMemcpy(d_in, h_in.data(), n * 2, hipMemcpyHostToDevice));
+    HH_CHECK_HIP(hipMemcpy(d_w, h_w.data(), h_w.size() * 2, hipMemcpyHostToDevice));
+    HH_CHECK_HIP(hipMemset(d_b, 0, 32 * 4));
+    HH_CHECK_HIP(hipMemset(d_st, 0, 64 * 8));
+    BBParams p{};
+    p.in = d_in; p.in_cs = 32; p.out = d_out; p.out_cs = 32; p.w1 = d_w; p.w2 = d_w; p.b1 = d_b; p.b2 = d_b;
+    p.B = B; p.H = H; p.W = W; p.stamps = d_st;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HH_CHECK_HIP(hipGetDevice(&dev));
+    HH_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    hipStream_t st;
+    HH_CHECK_HIP(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    HH_CHECK_HIP(hipEventCreate(&e0));
+    HH_CHECK_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) HH_CHECK_HIP(bb_fused_launch(p, prop.multiProcessorCount, st));
+    HH_CHECK_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) HH_CHECK_HIP(bb_fused_launch(p, prop.multiProcessorCount, st));
+    HH_CHECK_HIP(hipEventRecord(e1, st));
+    HH_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    HH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / iters;
+    if (stamps64) HH_CHECK_HIP(hipMemcpy(stamps64, d_st, 64 * 8, hipMemcpyDeviceToHost));
+    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(st);
+    hipFree(d_in); hipFree(d_out); hipFree(d_w); hipFree(d_b); hipFree(d_st);
+    return 0;
+}

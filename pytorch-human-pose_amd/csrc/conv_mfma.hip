@@ -128,27 +128,52 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 
     ISSUE_LOADS(0);
 
-    // ---- accumulators start at bias (+ residual): the 8-byte residual gathers overlap the patch loads
+    // ---- accumulators start at bias (+ residual).  All of these loads are issued back to back (clamped
+    //      addresses instead of branches) so they overlap the patch loads instead of serialising on vmcnt(0).
     f32x16 acc[NT][PT];
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        const int oy = oy0 + (wp * PT + pt) * RPT + dy, ox = ox0 + dx;
-        const bool valid = oy < p.Ho && ox < p.Wo;
-        const size_t pix = ((size_t)b * p.Hob + (oy * p.osy + p.ooy)) * p.Wob + (ox * p.osx + p.oox);
+    {
+        float4 bs[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 8 * g + 4 * h;
-                const float4 bs = *reinterpret_cast<const float4 *>(p.bias + c0);
-                float v0 = bs.x, v1 = bs.y, v2 = bs.z, v3 = bs.w;
-                if (p.res && valid && c0 < p.cout_store) {
-                    const uint2 rv = *reinterpret_cast<const uint2 *>(p.res + pix * p.res_cs + p.res_coff + c0);
-                    v0 += bf16_lo(rv.x); v1 += bf16_hi(rv.x); v2 += bf16_lo(rv.y); v3 += bf16_hi(rv.y);
-                }
-                acc[nt][pt][4 * g + 0] = v0; acc[nt][pt][4 * g + 1] = v1;
-                acc[nt][pt][4 * g + 2] = v2; acc[nt][pt][4 * g + 3] = v3;
+            for (int g = 0; g < 4; ++g)
+                bs[nt][g] = *reinterpret_cast<const float4 *>(p.bias + cg * COUT_T + (wc * NT + nt) * 32 + 8 * g + 4 * h);
+        uint2 rv[PT][NT][4];
+        if (p.res) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int oy = oy0 + (wp * PT + pt) * RPT + dy, ox = ox0 + dx;
+                const bool valid = oy < p.Ho && ox < p.Wo;
+                const size_t pix = valid ? ((size_t)b * p.Hob + (oy * p.osy + p.ooy)) * p.Wob + (ox * p.osx + p.oox) : 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 8 * g + 4 * h;
+                        const bool ok = valid && c0 < p.cout_store;
+                        const uint2 v = *reinterpret_cast<const uint2 *>(p.res + pix * p.res_cs + p.res_coff + (ok ? c0 : 0));
+                        rv[pt][nt][g] = ok ? v : make_uint2(0u, 0u);
+                    }
             }
+        } else {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rv[pt][nt][g] = make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[nt][pt][4 * g + 0] = bs[nt][g].x + bf16_lo(rv[pt][nt][g].x);
+                    acc[nt][pt][4 * g + 1] = bs[nt][g].y + bf16_hi(rv[pt][nt][g].x);
+                    acc[nt][pt][4 * g + 2] = bs[nt][g].z + bf16_lo(rv[pt][nt][g].y);
+                    acc[nt][pt][4 * g + 3] = bs[nt][g].w + bf16_hi(rv[pt][nt][g].y);
+                }
     }
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -156,29 +181,43 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
         __syncthreads();
         if (chunk + 1 < nchunks) ISSUE_LOADS(chunk + 1);
 
-        // ---- MFMA over taps x 16-channel k-steps
+        // ---- MFMA over taps x 16-channel k-steps; the LDS fragment reads of step s+1 are issued before the
+        //      MFMAs of step s (sched_group_barrier pins that order), so ds_read latency hides under MFMA issue.
+        {
+            constexpr int NSTEP = KS * KS * (KC / 16);
+            u32x4 fa[2][NT], fb[2][PT];
+            auto ldf = [&](int st, int buf) {
+                const int tap = st / (KC / 16), kk = st % (KC / 16), ky = tap / KS, kx = tap % KS;
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < KS; ++kx)
-#pragma unroll
-                for (int kk = 0; kk < KC / 16; ++kk) {
-                    bf16x8 a[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int unit = (((ky * KS + kx) * C8 + kk * 2 + h) * COUT_T) + (wc * NT + nt) * 32 + r;
-                        a[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(lds_w + unit * 16));
-                    }
-#pragma unroll
-                    for (int pt = 0; pt < PT; ++pt) {
-                        const int row = (wp * PT + pt) * RPT + dy;
-                        const int addr = ((row * S + ky) * PW + dx * S + kx) * PS + kk * 32 + h * 16;
-                        const bf16x8 bv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(lds_p + addr));
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt], bv, acc[nt][pt], 0, 0, 0);
-                    }
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int unit = ((tap * C8 + kk * 2 + h) * COUT_T) + (wc * NT + nt) * 32 + r;
+                    fa[buf][nt] = *reinterpret_cast<const u32x4 *>(lds_w + unit * 16);
                 }
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const int row = (wp * PT + pt) * RPT + dy;
+                    const int addr = ((row * S + ky) * PW + dx * S + kx) * PS + kk * 32 + h * 16;
+                    fb[buf][pt] = *reinterpret_cast<const u32x4 *>(lds_p + addr);
+                }
+            };
+            ldf(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NT + PT, 0);
+            static_for<NSTEP>([&](auto ic) {
+                constexpr int st = decltype(ic)::value;
+                if (st + 1 < NSTEP) {
+                    ldf(st + 1, (st + 1) & 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NT + PT, 0);
+                }
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st & 1][nt]),
+                                                                              __builtin_bit_cast(bf16x8, fb[st & 1][pt]),
+                                                                              acc[nt][pt], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, NT * PT, 0);
+            });
+        }
         __syncthreads();  // every wave is done reading this chunk (LDS is rewritten next)
     }
 

@@ -155,6 +155,25 @@ struct Builder {
     {
         return conv(L(p + "." + c, p + "." + b, cin, cout, ks, stride), in, out, relu, res);
     }
+    // four BasicBlocks "<prefix>.<u>" on tensor x with scratch m (both C channels); result ends in x
+    void basic_blocks(const std::string &prefix, int C, int x, int m)
+    {
+        for (int u = 0; u < 4; ++u) {
+            const std::string up = prefix + "." + std::to_string(u);
+            if (C == 32) {  // fused kernel, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
+                Op o;
+                o.kind = OP_BB;
+                o.layer = L(up + ".conv1", up + ".bn1", C, C, 3, 1);
+                o.layer2 = L(up + ".conv2", up + ".bn2", C, C, 3, 1);
+                o.in = (u & 1) ? m : x;
+                o.out = (u & 1) ? x : m;
+                n.ops.push_back(o);
+            } else {
+                cb(up, "conv1", "bn1", C, C, 3, 1, x, m, 1);
+                cb(up, "conv2", "bn2", C, C, 3, 1, m, x, 1, x);
+            }
+        }
+    }
     void tap(const std::string &name, int tensor, int C, int coff = 0)
     {
         TapInfo t;
@@ -215,12 +234,7 @@ struct Builder {
                 // HighResolutionBlock: 4 BasicBlocks per scale (hrnet.py:77-124,154-163); conv2 adds the
                 // identity and writes in place (each lane reads the residual of the pixel it overwrites).
                 const std::string hp = sp + ".blocks." + std::to_string(2 * b);
-                for (int i = 0; i < nsc; ++i)
-                    for (int u = 0; u < 4; ++u) {
-                        const std::string up = hp + ".scales_blocks." + std::to_string(i) + "." + std::to_string(u);
-                        cb(up, "conv1", "bn1", w[i], w[i], 3, 1, x[i], m[i], 1);
-                        cb(up, "conv2", "bn2", w[i], w[i], 3, 1, m[i], x[i], 1, x[i]);
-                    }
+                for (int i = 0; i < nsc; ++i) basic_blocks(hp + ".scales_blocks." + std::to_string(i), w[i], x[i], m[i]);
                 for (int i = 0; i < nsc; ++i)
                     tap("stages." + std::to_string(s) + ".blocks." + std::to_string(2 * b) + "#" + std::to_string(i), x[i], w[i]);
                 // FusionLayer (hrnet.py:166-229)
@@ -282,11 +296,7 @@ struct Builder {
                 Op &o = conv(l, CAT, DF, 1);
                 o.scatter = 1;
             }
-        for (int r = 0; r < 4; ++r) {
-            const std::string rp = dp + ".resid_blocks." + std::to_string(r);
-            cb(rp, "conv1", "bn1", C, C, 3, 1, DF, DM, 1);
-            cb(rp, "conv2", "bn2", C, C, 3, 1, DM, DF, 1, DF);
-        }
+        basic_blocks(dp + ".resid_blocks", C, DF, DM);
         tap("deconv#0", DF, C);
         {
             Op &o = conv(L(dp + ".final_layer", "", C, K, 1, 1, dp + ".final_layer.bias"), DF, -1, 0);
@@ -323,6 +333,14 @@ int hh_net::finalize()
     for (auto &p : params)
         if (!p.loaded && !p.counter) { hh_set_error("hh_finalize: parameter never loaded: " + p.name); return 1; }
     HH_CHECK_HIP(conv_init());
+    HH_CHECK_HIP(bb_fused_init());
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        HH_CHECK_HIP(hipGetDevice(&dev));
+        HH_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        num_cus = prop.multiProcessorCount;
+    }
     auto get = [&](const std::string &name) -> const std::vector<float> & { return params[param_index.at(name)].data; };
     for (auto &l : layers) {
         const int cin_pad0 = round_up(l.cin, 16), coutp = round_up(l.cout, 32);
@@ -464,6 +482,31 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                                         hipMemcpyDeviceToDevice, s));
             break;
         }
+        case OP_BB: {
+            const ConvLayer &l1 = layers[op.layer], &l2 = layers[op.layer2];
+            const TensorDesc &ti = tensors[op.in], &to = tensors[op.out];
+            BBParams p{};
+            p.in = ti.ptr; p.in_cs = ti.C; p.out = to.ptr; p.out_cs = to.C;
+            p.w1 = l1.d_w; p.w2 = l2.d_w; p.b1 = l1.d_bias; p.b2 = l2.d_bias;
+            p.B = B; p.H = H >> ti.shift; p.W = W >> ti.shift;
+            ProfRecord *pr = nullptr;
+            if (prof_enabled) {
+                if (prof_used == prof.size()) {
+                    ProfRecord r{};
+                    HH_CHECK_HIP(hipEventCreate(&r.e0));
+                    HH_CHECK_HIP(hipEventCreate(&r.e1));
+                    prof.push_back(r);
+                }
+                pr = &prof[prof_used++];
+                pr->op = (int)(&op - ops.data());
+                pr->cfg = HH_CFG_BB_FUSED;
+                pr->flops = 2.0 * 2.0 * B * p.H * p.W * 32.0 * 32.0 * 9.0;
+                HH_CHECK_HIP(hipEventRecord(pr->e0, s));
+            }
+            HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
+            if (pr) HH_CHECK_HIP(hipEventRecord(pr->e1, s));
+            break;
+        }
         case OP_CONV: {
             const ConvLayer &l = layers[op.layer];
             const TensorDesc &ti = tensors[op.in];
@@ -553,6 +596,11 @@ double hh_net::flops(int B, int H, int W) const
 {
     double macs = 0;
     for (const Op &op : ops) {
+        if (op.kind == OP_BB) {
+            const TensorDesc &ti = tensors[op.in];
+            macs += 2.0 * (double)(H >> ti.shift) * (W >> ti.shift) * 32.0 * 32.0 * 9.0;
+            continue;
+        }
         if (op.kind != OP_CONV) continue;
         const ConvLayer &l = layers[op.layer];
         const TensorDesc &ti = tensors[op.in];

@@ -43,11 +43,11 @@ struct TensorDesc {
     bool zero_init = false;
 };
 
-enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP };
+enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB };
 
 struct Op {
     OpKind kind = OP_CONV;
-    int layer = -1;
+    int layer = -1, layer2 = -1;  // layer2: second conv of a fused BasicBlock
     int in = -1, in_coff = 0;
     int out = -1, out_coff = 0;
     int res = -1, res_coff = 0;
@@ -89,6 +89,7 @@ struct hh_net {
     std::vector<TapInfo> taps;
     bool taps_enabled = false;
     bool finalized = false;
+    int num_cus = 256;
     int rB = 0, rH = 0, rW = 0;  // reserved shape
     int lastB = 0, lastH = 0, lastW = 0;
     int64_t ws_bytes = 0;

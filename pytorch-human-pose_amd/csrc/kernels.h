@@ -48,6 +48,20 @@ const ConvConfig &conv_config(int i);
 hipError_t conv_launch(int cfg_index, const ConvParams &p, hipStream_t stream);
 hipError_t conv_init();  // raises the dynamic-LDS limit of every instantiation
 
+// Fused 32-channel BasicBlock (basicblock_fused.hip): out = relu(conv2(relu(conv1(in))) + in), BN folded.
+struct BBParams {
+    const bf16_raw *in; int in_cs;   // [B,H,W,in_cs], channels 0..31
+    bf16_raw *out; int out_cs;       // must not alias `in` (tiles read a 2-pixel halo of their neighbours)
+    const bf16_raw *w1, *w2;         // packed as conv_mfma family (KS=3,S=1,KC=32,NT=1): [tap][4][32][8]
+    const float *b1, *b2;            // [32]
+    int B, H, W;
+    int tiles_x, tiles_y, ntiles;    // filled by bb_fused_launch
+    unsigned long long *stamps;      // diagnostic build (-DHH_STAMP) only
+};
+#define HH_CFG_BB_FUSED 100  // pseudo instantiation index used by the profiler
+hipError_t bb_fused_init();
+hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s);
+
 // fp32 NCHW [B,3,H,W] -> bf16 NHWC [B,H,W,16] (channels 3..15 zero)
 hipError_t launch_in_convert(const float *in, bf16_raw *out, int B, int H, int W, hipStream_t s);
 

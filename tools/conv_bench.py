@@ -1,0 +1,20 @@
+"""Micro-benchmark of single conv shapes through hh_debug_conv_bench (GPU box).
+usage: conv_bench.py [case ...]   case = cfg,B,H,W,cin,cout,res"""
+import ctypes as C, importlib, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+pkg = importlib.import_module("pytorch-human-pose_amd")
+lib = pkg._lib.load()
+cases = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [
+    (0, 32, 128, 128, 32, 32, 1), (0, 32, 256, 256, 32, 32, 1), (1, 32, 64, 64, 64, 64, 1), (1, 32, 32, 32, 128, 128, 1),
+    (2, 32, 16, 16, 256, 256, 1), (1, 32, 128, 128, 64, 64, 0), (9, 32, 128, 128, 64, 256, 1), (9, 32, 128, 128, 256, 64, 0)]
+cv = (C.c_int * 7)()
+for cfg, B, H, W, cin, cout, res in cases:
+    ms = C.c_float()
+    pkg._lib.check(lib.hh_debug_conv_bench(cfg, B, H, W, cin, cout, res, 1, 50, C.byref(ms)))
+    lib.hh_conv_config(cfg, cv)
+    ks, s = cv[0], cv[1]
+    ho, wo = (H // 2, W // 2) if s == 2 else (H, W)
+    fl = 2.0 * B * ho * wo * cin * cout * ks * ks
+    by = 2.0 * B * (H * W * cin + ho * wo * cout * (2 if res else 1))
+    print(f"cfg{tuple(cv)} B{B} {H}x{W} {cin}->{cout} res={res}: {ms.value*1e3:8.1f} us  {fl/ms.value/1e9:7.1f} TF/s  {by/ms.value/1e9:7.2f} TB/s(min traffic)")
