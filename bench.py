@@ -45,12 +45,22 @@ def collect_profile(pkg, net):
     return per_cfg
 
 
-def cpu_baseline(pkg, sd, maps, fwd_images=2, dec_images=8):
+def traffic_for(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/traffic_r01.json)."""
+    try:
+        with open(os.path.join(REPO, "profiles", "traffic_r01.json")) as f:
+            return json.load(f)["bytes_per_launch"].get(kernel_name)
+    except OSError:
+        return None
+
+
+def cpu_baseline(pkg, sd, maps, fwd_images=4, dec_images=8):
     """The oracle (a port of the reference's path, kind="port") timed on this host."""
     from oracle import decode as orc
     from oracle import forward as ofw
 
-    nthreads = torch.get_num_threads()
+    nthreads = min(32, os.cpu_count() or 1)  # torch's CPU convs stop scaling (and regress) far below 128 threads
+    torch.set_num_threads(nthreads)
     x = torch.from_numpy(pkg.synth.synth_images(fwd_images, 512, 512, 0))
     with torch.no_grad():
         ofw.higher_hrnet(x[:1], sd, 17)  # warm-up
@@ -189,7 +199,9 @@ def main():
             dom = max(per_cfg, key=lambda c: per_cfg[c]["ms"])
             d = per_cfg[dom]
             cfgv = (C.c_int * 7)()
-            lib.hh_conv_config(dom, cfgv)
+            kname = "bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)"
+            if lib.hh_conv_config(dom, cfgv) == 0:
+                kname = "conv_mfma_kernel<KS=%d,S=%d,KC=%d,NT=%d,WC=%d,PT=%d,TW=%d>" % tuple(cfgv)
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             total_ms = sum(v["ms"] for v in per_cfg.values())
             line["roofline"] = {
@@ -198,8 +210,8 @@ def main():
                 "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
-                "traffic": None,
-                "kernel": "conv_mfma_kernel<KS=%d,S=%d,KC=%d,NT=%d,WC=%d,PT=%d,TW=%d>" % tuple(cfgv),
+                "traffic": traffic_for(kname),
+                "kernel": kname,
                 "launches": d["n"],
                 "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 2),
                 "avg_launch_gflop": round(d["flops"] / d["n"] / 1e9, 3),

@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     constexpr int PATCH_BYTES = (PH * PW * PS + 15) & ~15;
     constexpr int P_UNITS = PH * PW * C8;           // 16-byte units of one input patch chunk
     constexpr int W_UNITS = KS * KS * C8 * COUT_T;  // 16-byte units of one weight chunk
-    constexpr int NPL = (P_UNITS + 255) / 256, NWL = (W_UNITS + 255) / 256;
-    constexpr int OS = COUT_T * 2 + 16;             // bytes per pixel of the staged output tile
-    constexpr int O8 = COUT_T / 8;
+    constexpr int NPL = (P_UNITS + 255) / 256, NWL = (W_UNITS + 255) / 256, NL = NPL + NWL;
+    constexpr int NSTEP = KS * KS * (KC / 16);      // MFMA k-steps per chunk
+    constexpr int LPS = (NL + NSTEP - 1) / NSTEP;   // prefetch loads issued per k-step
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *lds_p = smem;
@@ -85,51 +85,55 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     const int dy = r / TW, dx = r % TW;
 
     const int nchunks = p.cin / KC;
-    const bf16_raw *in_b = p.in + (size_t)b * p.Hin * p.Win * p.in_cs + p.in_coff;
     const u32x4 *w_cg = reinterpret_cast<const u32x4 *>(p.w) + (size_t)cg * nchunks * W_UNITS;
 
-    // ---- register-staged loads: every global load of a chunk is issued before any LDS write, and the
-    //      next chunk's loads are issued before the current chunk's MFMAs (latency hides under compute).
+    // ---- chunk-invariant geometry of this thread's staging units: source pointer of chunk 0 and an
+    //      "inside the image" bit per unit (outside = conv zero padding, applied when the unit is written to LDS)
+    const bf16_raw *psrc[NPL];
+    unsigned pmask = 0;
+    {
+        const bf16_raw *in_b = p.in + (size_t)b * p.Hin * p.Win * p.in_cs + p.in_coff;
+        static_for<NPL>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int u = tid + 256 * i;
+            const int pix = u / C8, part = u % C8;
+            const int iy = iy0 + pix / PW, ix = ix0 + pix % PW;
+            const bool ok = u < P_UNITS && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+            psrc[i] = ok ? in_b + ((size_t)iy * p.Win + ix) * p.in_cs + part * 8 : in_b;
+            pmask |= ok ? (1u << i) : 0u;
+        });
+    }
+    // ---- register staging.  load_unit(j, chunk) issues the j-th 16-byte load of a chunk (patch units first, then
+    //      weight units) and never looks at the result, so no s_waitcnt lands next to it.
     u32x4 preg[NPL], wreg[NWL];
-#define ISSUE_LOADS(chunk_)                                                                                        \
-    {                                                                                                              \
-        const int ch_ = (chunk_);                                                                                  \
-        static_for<NPL>([&](auto ic) {                                                                             \
-            constexpr int i = decltype(ic)::value;                                                                 \
-            const int u = tid + 256 * i;                                                                           \
-            const int pix = u / C8, part = u % C8;                                                                 \
-            const int iy = iy0 + pix / PW, ix = ix0 + pix % PW;                                                    \
-            const bool ok = u < P_UNITS && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;                         \
-            const u32x4 *src = reinterpret_cast<const u32x4 *>(                                                    \
-                in_b + ((size_t)(ok ? iy : 0) * p.Win + (ok ? ix : 0)) * p.in_cs + ch_ * KC + part * 8);           \
-            const u32x4 v = *src; /* always-valid address; zero outside the image = conv padding */               \
-            preg[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};                                                                \
-        });                                                                                                        \
-        const u32x4 *wsrc = w_cg + (size_t)ch_ * W_UNITS;                                                          \
-        static_for<NWL>([&](auto ic) {                                                                             \
-            constexpr int i = decltype(ic)::value;                                                                 \
-            const int u = tid + 256 * i;                                                                           \
-            wreg[i] = wsrc[u < W_UNITS ? u : 0];                                                                   \
-        });                                                                                                        \
-    }
-#define WRITE_LDS()                                                                                                \
-    {                                                                                                              \
-        static_for<NPL>([&](auto ic) {                                                                             \
-            constexpr int i = decltype(ic)::value;                                                                 \
-            const int u = tid + 256 * i;                                                                           \
-            if (u < P_UNITS) *reinterpret_cast<u32x4 *>(lds_p + (u / C8) * PS + (u % C8) * 16) = preg[i];          \
-        });                                                                                                        \
-        static_for<NWL>([&](auto ic) {                                                                             \
-            constexpr int i = decltype(ic)::value;                                                                 \
-            const int u = tid + 256 * i;                                                                           \
-            if (u < W_UNITS) reinterpret_cast<u32x4 *>(lds_w)[u] = wreg[i];                                        \
-        });                                                                                                        \
-    }
+    auto load_unit = [&](auto jc, int chunk) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < NPL) {
+            preg[j] = *reinterpret_cast<const u32x4 *>(psrc[j] + ((pmask >> j) & 1u ? chunk * KC : 0));
+        } else if constexpr (j < NL) {
+            constexpr int i = j - NPL;
+            const int u = tid + 256 * i;
+            wreg[i] = w_cg[(size_t)chunk * W_UNITS + (u < W_UNITS ? u : 0)];
+        }
+    };
+    auto write_lds = [&]() {
+        static_for<NPL>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int u = tid + 256 * i;
+            if (u < P_UNITS)
+                *reinterpret_cast<u32x4 *>(lds_p + (u / C8) * PS + (u % C8) * 16) = (pmask >> i) & 1u ? preg[i] : u32x4{0u, 0u, 0u, 0u};
+        });
+        static_for<NWL>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int u = tid + 256 * i;
+            if (u < W_UNITS) reinterpret_cast<u32x4 *>(lds_w)[u] = wreg[i];
+        });
+    };
 
-    ISSUE_LOADS(0);
+    static_for<NL>([&](auto jc) { load_unit(jc, 0); });
 
-    // ---- accumulators start at bias (+ residual).  All of these loads are issued back to back (clamped
-    //      addresses instead of branches) so they overlap the patch loads instead of serialising on vmcnt(0).
+    // ---- accumulators start at bias (+ residual).  The residual is read 16 bytes per lane (couts 16m+8h..+7 of the
+    //      lane's pixel) and the two half-waves exchange halves with v_permlane32_swap into the MFMA C layout.
     f32x16 acc[NT][PT];
     {
         float4 bs[NT][4];
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 bs[nt][g] = *reinterpret_cast<const float4 *>(p.bias + cg * COUT_T + (wc * NT + nt) * 32 + 8 * g + 4 * h);
-        uint2 rv[PT][NT][4];
+        u32x4 rv[PT][NT][2];
         if (p.res) {
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
@@ -148,43 +152,42 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 8 * g + 4 * h;
+                    for (int m = 0; m < 2; ++m) {
+                        const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 16 * m + 8 * h;
                         const bool ok = valid && c0 < p.cout_store;
-                        const uint2 v = *reinterpret_cast<const uint2 *>(p.res + pix * p.res_cs + p.res_coff + (ok ? c0 : 0));
-                        rv[pt][nt][g] = ok ? v : make_uint2(0u, 0u);
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(p.res + pix * p.res_cs + p.res_coff + (ok ? c0 : 0));
+                        rv[pt][nt][m] = ok ? v : u32x4{0u, 0u, 0u, 0u};
                     }
             }
-        } else {
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) rv[pt][nt][g] = make_uint2(0u, 0u);
         }
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    acc[nt][pt][4 * g + 0] = bs[nt][g].x + bf16_lo(rv[pt][nt][g].x);
-                    acc[nt][pt][4 * g + 1] = bs[nt][g].y + bf16_hi(rv[pt][nt][g].x);
-                    acc[nt][pt][4 * g + 2] = bs[nt][g].z + bf16_lo(rv[pt][nt][g].y);
-                    acc[nt][pt][4 * g + 3] = bs[nt][g].w + bf16_hi(rv[pt][nt][g].y);
+                for (int m = 0; m < 2; ++m) {
+                    unsigned x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+                    if (p.res) {
+                        auto s0 = __builtin_amdgcn_permlane32_swap(rv[pt][nt][m][0], rv[pt][nt][m][2], false, false);
+                        auto s1 = __builtin_amdgcn_permlane32_swap(rv[pt][nt][m][1], rv[pt][nt][m][3], false, false);
+                        x0 = s0[0]; y0 = s0[1]; x1 = s1[0]; y1 = s1[1];
+                    }
+                    const float4 ba = bs[nt][2 * m], bb = bs[nt][2 * m + 1];
+                    acc[nt][pt][8 * m + 0] = ba.x + bf16_lo(x0); acc[nt][pt][8 * m + 1] = ba.y + bf16_hi(x0);
+                    acc[nt][pt][8 * m + 2] = ba.z + bf16_lo(x1); acc[nt][pt][8 * m + 3] = ba.w + bf16_hi(x1);
+                    acc[nt][pt][8 * m + 4] = bb.x + bf16_lo(y0); acc[nt][pt][8 * m + 5] = bb.y + bf16_hi(y0);
+                    acc[nt][pt][8 * m + 6] = bb.z + bf16_lo(y1); acc[nt][pt][8 * m + 7] = bb.w + bf16_hi(y1);
                 }
     }
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        WRITE_LDS();
+        write_lds();
         __syncthreads();
-        if (chunk + 1 < nchunks) ISSUE_LOADS(chunk + 1);
-
-        // ---- MFMA over taps x 16-channel k-steps; the LDS fragment reads of step s+1 are issued before the
-        //      MFMAs of step s (sched_group_barrier pins that order), so ds_read latency hides under MFMA issue.
+        const bool more = chunk + 1 < nchunks;
+        // ---- MFMA over taps x 16-channel k-steps.  LDS fragment reads run one k-step ahead (sched_group_barrier pins
+        //      the order) and the next chunk's global loads are spread over the k-steps, LPS per step: issued in a
+        //      burst they back-pressure the CU's load path (~10 B/cycle) and the MFMAs wait behind them.
         {
-            constexpr int NSTEP = KS * KS * (KC / 16);
             u32x4 fa[2][NT], fb[2][PT];
             auto ldf = [&](int st, int buf) {
                 const int tap = st / (KC / 16), kk = st % (KC / 16), ky = tap / KS, kx = tap % KS;
@@ -208,6 +211,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
                     ldf(st + 1, (st + 1) & 1);
                     __builtin_amdgcn_sched_group_barrier(0x100, NT + PT, 0);
                 }
+                if (more)
+                    static_for<LPS>([&](auto lc) {
+                        load_unit(std::integral_constant<int, st * LPS + decltype(lc)::value>{}, chunk + 1);
+                    });
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
@@ -218,60 +225,51 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
                 __builtin_amdgcn_sched_group_barrier(0x8, NT * PT, 0);
             });
         }
-        __syncthreads();  // every wave is done reading this chunk (LDS is rewritten next)
+        if (more) __syncthreads();  // every wave is done reading this chunk (LDS is rewritten next)
     }
 
-    // ---- epilogue: (ReLU) -> fp32 NCHW directly, bf16 NHWC through an LDS transpose so that every
-    //      lane stores 16 contiguous bytes and a tile row leaves as one contiguous run.
+    // ---- epilogue: (ReLU) -> fp32 NCHW directly, or bf16 NHWC with the half-waves paired by v_permlane32_swap so
+    //      that every lane stores 16 contiguous bytes (couts 16m+8h..+7 of its pixel) straight from registers.
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-        const int lp = ((wp * PT + pt) * RPT + dy) * TW + dx;  // pixel index inside the tile
         const int oy = oy0 + (wp * PT + pt) * RPT + dy, ox = ox0 + dx;
         const bool valid = oy < p.Ho && ox < p.Wo;
         const int Y = oy * p.osy + p.ooy, X = ox * p.osx + p.oox;
+        const size_t pix = ((size_t)b * p.Hob + Y) * p.Wob + X;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            if (p.relu)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v0 = acc[nt][pt][4 * g + 0], v1 = acc[nt][pt][4 * g + 1];
-                float v2 = acc[nt][pt][4 * g + 2], v3 = acc[nt][pt][4 * g + 3];
-                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                const int cl = (wc * NT + nt) * 32 + 8 * g + 4 * h;  // channel inside the WG's cout tile
-                if (p.out) {
-                    uint2 o; o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
-                    *reinterpret_cast<uint2 *>(smem + lp * OS + cl * 2) = o;
-                }
-                if (p.out_f32 && valid) {
-                    const int c0 = cg * COUT_T + cl;
-                    const size_t plane = (size_t)p.Hob * p.Wob;
-                    float *o = p.out_f32 + ((size_t)b * p.cout_real + c0) * plane + (size_t)Y * p.Wob + X;
-                    if (c0 + 0 < p.cout_real) o[0] = v0;
-                    if (c0 + 1 < p.cout_real) o[plane] = v1;
-                    if (c0 + 2 < p.cout_real) o[2 * plane] = v2;
-                    if (c0 + 3 < p.cout_real) o[3 * plane] = v3;
+                for (int i = 0; i < 16; ++i) acc[nt][pt][i] = fmaxf(acc[nt][pt][i], 0.f);
+            if (p.out) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const unsigned x0 = pack_bf16x2(acc[nt][pt][8 * m + 0], acc[nt][pt][8 * m + 1]);
+                    const unsigned x1 = pack_bf16x2(acc[nt][pt][8 * m + 2], acc[nt][pt][8 * m + 3]);
+                    const unsigned y0 = pack_bf16x2(acc[nt][pt][8 * m + 4], acc[nt][pt][8 * m + 5]);
+                    const unsigned y1 = pack_bf16x2(acc[nt][pt][8 * m + 6], acc[nt][pt][8 * m + 7]);
+                    auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                    const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 16 * m + 8 * h;
+                    if (valid && c0 < p.cout_store)
+                        *reinterpret_cast<u32x4 *>(p.out + pix * p.out_cs + p.out_coff + c0) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 }
             }
-    }
-    if (p.out) {
-        __syncthreads();
-        constexpr int O_UNITS = TH * TW * O8;
+            if (p.out_f32 && valid) {
+                const size_t plane = (size_t)p.Hob * p.Wob;
 #pragma unroll
-        for (int i = 0; i < (O_UNITS + 255) / 256; ++i) {
-            const int u = tid + 256 * i;
-            const int lp = u / O8, part = u % O8;
-            const int oy = oy0 + lp / TW, ox = ox0 + lp % TW;
-            const int c = cg * COUT_T + part * 8;
-            if (u < O_UNITS && oy < p.Ho && ox < p.Wo && c < p.cout_store) {
-                const size_t pix = ((size_t)b * p.Hob + (oy * p.osy + p.ooy)) * p.Wob + (ox * p.osx + p.oox);
-                *reinterpret_cast<uint4 *>(p.out + pix * p.out_cs + p.out_coff + c) =
-                    *reinterpret_cast<const uint4 *>(smem + lp * OS + part * 16);
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 8 * g + 4 * h;
+                    float *o = p.out_f32 + ((size_t)b * p.cout_real + c0) * plane + (size_t)Y * p.Wob + X;
+                    if (c0 + 0 < p.cout_real) o[0] = acc[nt][pt][4 * g + 0];
+                    if (c0 + 1 < p.cout_real) o[plane] = acc[nt][pt][4 * g + 1];
+                    if (c0 + 2 < p.cout_real) o[2 * plane] = acc[nt][pt][4 * g + 2];
+                    if (c0 + 3 < p.cout_real) o[3 * plane] = acc[nt][pt][4 * g + 3];
+                }
             }
         }
     }
 }
-
-#undef ISSUE_LOADS
-#undef WRITE_LDS
 
 // ---------------------------------------------------------------------------------------
 // Instantiation table. {KS, S, KC, NT, WC, PT, TW}

@@ -35,9 +35,7 @@ struct ConvConfig {
     size_t lds_bytes() const {
         int PH = (th() - 1) * S + KS, PW = (TW - 1) * S + KS;
         size_t patch = ((size_t)PH * PW * (KC * 2 + 16) + 15) & ~(size_t)15;
-        size_t stage = patch + (size_t)KS * KS * KC * cout_t() * 2;
-        size_t otile = (size_t)th() * TW * (cout_t() * 2 + 16);  // epilogue transpose buffer (reuses the same LDS)
-        return stage > otile ? stage : otile;
+        return patch + (size_t)KS * KS * KC * cout_t() * 2;
     }
 };
 
