@@ -9,9 +9,9 @@ One "step" = one pass of the hot path over one batch of synthetic input resident
 Multi-GPU: the path shards by image (no collective on the data path); every rank runs the same
 per-GPU batch (weak scaling), timing is barrier + synchronize on both sides, max over ranks.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live inside the timed region: steps 1..K-1 replay the
-captured hipGraph, the K-th (last) timed step runs eagerly with HIP events bracketing every convolution
-launch on the launch stream (hh_profile_*); the dominant kernel instantiation is the one with the largest
+Prints ONE JSON line (rank 0).  `roofline` is measured live inside the timed region: steps 1..K-1 run as they would in
+production (eager launches, branch lanes on internal streams), the K-th (last) timed step runs single-lane with HIP
+events bracketing every convolution launch on the launch stream (hh_profile_*); the dominant kernel instantiation is the one with the largest
 summed time in that step.  `cpu_baseline` times the CPU oracle (oracle/) on a bounded sample on rank 0.
 """
 import argparse
@@ -91,7 +91,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--people", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="hipGraph replay in the timed region, no per-launch events")
+    ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events in the last timed step")
+    ap.add_argument("--sequential", action="store_true", help="issue decode behind the forward on one stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,19 +121,30 @@ def main():
     parser = pkg.MPPEHeatmapParser(K, 30, 0.05, 0.5)
     lib = pkg._lib.load()
 
+    side = torch.cuda.Stream(dev)   # forward stream (the engine forks its branch lanes from it)
+    side2 = torch.cuda.Stream(dev)  # decode stream
+    outs = (torch.empty(B, 2 * K, H // 4, W // 4, device=dev), torch.empty(B, K, H // 2, W // 2, device=dev))
+
     def step():
-        out = net.forward_raw(images)
-        dec = parser.decode_batch_device(hm_q, hm_h, [tags], adjust=True, refine=True)
+        # The two halves of a step have no data dependency (forward consumes images, decode consumes maps -- in
+        # serving, decode of batch i runs beside the forward of batch i+1), so they are issued on two streams
+        # unless --sequential is given.
+        out = net.forward_raw(images, outs)
+        if args.sequential:
+            dec = parser.decode_batch_device(hm_q, hm_h, [tags], adjust=True, refine=True)
+        else:
+            with torch.cuda.stream(side2):
+                dec = parser.decode_batch_device(hm_q, hm_h, [tags], adjust=True, refine=True)
         return out, dec
 
     stream = torch.cuda.current_stream(dev)
-    side = torch.cuda.Stream(dev)  # hipGraph capture needs a non-default stream
     with torch.cuda.stream(side):
         profile = not args.no_profile
         net.use_graph = True
         for _ in range(args.warmup):
             step()
         side.synchronize()
+        side2.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -150,10 +162,10 @@ def main():
         lib.hh_profile_enable(net._h, 0)
         # split of the step (not part of the timed region): forward alone / decode alone, graph replay
         net.use_graph = True
-        for fn in (lambda: net.forward_raw(images), lambda: parser.decode_batch_device(hm_q, hm_h, [tags])):
+        for fn in (lambda: net.forward_raw(images, outs), lambda: parser.decode_batch_device(hm_q, hm_h, [tags])):
             fn()
         parts = []
-        for fn in (lambda: net.forward_raw(images), lambda: parser.decode_batch_device(hm_q, hm_h, [tags])):
+        for fn in (lambda: net.forward_raw(images, outs), lambda: parser.decode_batch_device(hm_q, hm_h, [tags])):
             side.synchronize()
             t1 = time.perf_counter()
             for _ in range(5):
@@ -192,7 +204,10 @@ def main():
                 "forward_ms": round(parts[0] * 1e3, 3),
                 "decode_ms": round(parts[1] * 1e3, 3),
                 "forward_tflops": round(net.forward_flops(B, H, W) / parts[0] / 1e12, 1),
-                "timed_region": "hipGraph replay; last step eager with per-conv HIP events" if profile else "hipGraph replay",
+                "streams": "forward and decode issued back to back on one stream" if args.sequential else
+                           "forward (+3 internal branch lanes) and decode on two streams",
+                "timed_region": "eager multi-lane launches; last step single-lane with per-conv HIP events" if profile
+                                else "eager multi-lane launches",
             },
         }
         if per_cfg:

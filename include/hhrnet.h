@@ -61,6 +61,10 @@ int64_t hh_workspace_bytes(const hh_net *net);
 int hh_forward(hh_net *net, const float *images, int B, int H, int W, float *init_heatmaps, float *deconv_heatmaps,
                int use_graph, void *stream);
 
+/* Multi-lane execution (default on): independent resolution branches / fusion outputs are launched on
+ * internal HIP streams forked from and joined back to `stream` with events.  0 = everything on `stream`. */
+int hh_set_multi_lane(hh_net *net, int enable);
+
 /* Algorithmic conv/deconv FLOPs (2*MACs) of one forward at this shape -- SURVEY.md §8d.  */
 double hh_forward_flops(const hh_net *net, int B, int H, int W);
 

@@ -46,6 +46,7 @@ def _sig(lib):
         "hh_forward": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, vp]),
         "hh_forward_flops": (dbl, [vp, i32, i32, i32]),
         "hh_set_taps": (i32, [vp, i32]),
+        "hh_set_multi_lane": (i32, [vp, i32]),
         "hh_num_taps": (i32, [vp]),
         "hh_tap_name": (cp, [vp, i32]),
         "hh_tap_shape": (i32, [vp, i32, pi64]),

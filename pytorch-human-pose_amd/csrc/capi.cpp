@@ -64,6 +64,13 @@ int hh_forward(hh_net *net, const float *images, int B, int H, int W, float *ini
 }
 double hh_forward_flops(const hh_net *net, int B, int H, int W) { return net->flops(B, H, W); }
 
+int hh_set_multi_lane(hh_net *net, int enable)
+{
+    net->multi_lane = enable != 0;
+    for (auto &g : net->graphs) hipGraphExecDestroy(g.exec);
+    net->graphs.clear();
+    return 0;
+}
 int hh_set_taps(hh_net *net, int enable) { net->taps_enabled = enable != 0; return 0; }
 int hh_num_taps(const hh_net *net) { return (int)net->taps.size(); }
 const char *hh_tap_name(const hh_net *net, int i) { return (i >= 0 && i < (int)net->taps.size()) ? net->taps[i].name.c_str() : nullptr; }

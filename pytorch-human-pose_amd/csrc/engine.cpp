@@ -4,6 +4,7 @@
 #include "engine.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 static thread_local std::string g_err;
@@ -43,7 +44,14 @@ int hh_net::add_param(const std::string &name, std::vector<int64_t> shape, bool 
 namespace {
 struct Builder {
     hh_net &n;
+    int lane = 0;  // lane given to the ops created next
     explicit Builder(hh_net &net) : n(net) {}
+    void join(int nlanes)
+    {
+        Op o;
+        o.kind = OP_JOIN; o.nlanes = nlanes;
+        n.ops.push_back(o);
+    }
 
     // ---- parameter registration in the reference's state_dict order
     void p_conv(const std::string &name, int cin, int cout, int k, bool bias = false)
@@ -145,7 +153,7 @@ struct Builder {
     Op &conv(int layer, int in, int out, int relu, int res = -1)
     {
         Op o;
-        o.kind = OP_CONV; o.layer = layer; o.in = in; o.out = out; o.relu = relu; o.res = res;
+        o.kind = OP_CONV; o.layer = layer; o.in = in; o.out = out; o.relu = relu; o.res = res; o.lane = lane;
         n.ops.push_back(o);
         return n.ops.back();
     }
@@ -167,6 +175,7 @@ struct Builder {
                 o.layer2 = L(up + ".conv2", up + ".bn2", C, C, 3, 1);
                 o.in = (u & 1) ? m : x;
                 o.out = (u & 1) ? x : m;
+                o.lane = lane;
                 n.ops.push_back(o);
             } else {
                 cb(up, "conv1", "bn1", C, C, 3, 1, x, m, 1);
@@ -180,7 +189,7 @@ struct Builder {
         t.name = name; t.tensor = tensor; t.coff = coff; t.C = C;
         n.taps.push_back(t);
         Op o;
-        o.kind = OP_TAP; o.tap = (int)n.taps.size() - 1;
+        o.kind = OP_TAP; o.tap = (int)n.taps.size() - 1; o.lane = lane;
         n.ops.push_back(o);
     }
 
@@ -217,8 +226,10 @@ struct Builder {
         x[0] = T(w[0], 2); x[1] = T(w[1], 3);
         {
             const std::string tp = bb + ".stages.0.transition_layer.transition_blocks";
-            cb(tp + ".0", "0", "1", 256, w[0], 3, 1, Y, x[0], 1);
-            cb(tp + ".1", "0", "1", 256, w[1], 3, 2, Y, x[1], 1);
+            join(2);
+            lane = 0; cb(tp + ".0", "0", "1", 256, w[0], 3, 1, Y, x[0], 1);
+            lane = 1; cb(tp + ".1", "0", "1", 256, w[1], 3, 2, Y, x[1], 1);
+            lane = 0;
         }
         tap("stages.0#0", x[0], w[0]);
         tap("stages.0#1", x[1], w[1]);
@@ -234,7 +245,12 @@ struct Builder {
                 // HighResolutionBlock: 4 BasicBlocks per scale (hrnet.py:77-124,154-163); conv2 adds the
                 // identity and writes in place (each lane reads the residual of the pixel it overwrites).
                 const std::string hp = sp + ".blocks." + std::to_string(2 * b);
-                for (int i = 0; i < nsc; ++i) basic_blocks(hp + ".scales_blocks." + std::to_string(i), w[i], x[i], m[i]);
+                for (int i = 0; i < nsc; ++i) {  // branches are independent (hrnet.py:154-163): one lane each
+                    lane = i;
+                    basic_blocks(hp + ".scales_blocks." + std::to_string(i), w[i], x[i], m[i]);
+                }
+                lane = 0;
+                join(nsc);  // every fusion output reads every branch
                 for (int i = 0; i < nsc; ++i)
                     tap("stages." + std::to_string(s) + ".blocks." + std::to_string(2 * b) + "#" + std::to_string(i), x[i], w[i]);
                 // FusionLayer (hrnet.py:166-229)
@@ -242,10 +258,11 @@ struct Builder {
                 const bool last = s == 3 && b == nblocks[s] - 1;
                 const int nout = last ? 1 : nsc;
                 for (int i = 0; i < nout; ++i) {
+                    lane = i;  // output i only writes its own tensors; it feeds branch i of the next block directly
                     const int OUT = last ? CAT : f[i];
                     int cur = x[i];
                     Op up;
-                    up.kind = OP_UPADD; up.in = x[i]; up.out = OUT; up.C = w[i]; up.relu = (i == 0);
+                    up.kind = OP_UPADD; up.in = x[i]; up.out = OUT; up.C = w[i]; up.relu = (i == 0); up.lane = lane;
                     for (int j = i + 1; j < nsc; ++j) {  // low -> high: 1x1 conv + BN at low res
                         const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
                         const int u = T(w[i], 2 + j);
@@ -265,6 +282,7 @@ struct Builder {
                         cur = OUT;
                     }
                 }
+                lane = 0;
                 if (!last)
                     for (int i = 0; i < nout; ++i) std::swap(x[i], f[i]);
                 for (int i = 0; i < nout; ++i)
@@ -274,9 +292,13 @@ struct Builder {
             if (s < 3) {  // TransitionLayer: only the new lowest branch has parameters (hrnet.py:262-283)
                 const std::string q = sp + ".transition_layer.transition_blocks." + std::to_string(nsc);
                 x[nsc] = T(w[nsc], 2 + nsc);
+                join(nsc + 1);
+                lane = nsc;  // the new branch starts on its own lane
                 cb(q, "0", "1", w[nsc - 1], w[nsc], 3, 2, x[nsc - 1], x[nsc], 1);
+                lane = 0;
                 for (int i = 0; i <= nsc; ++i) tap("stages." + std::to_string(s) + "#" + std::to_string(i), x[i], w[i]);
             } else {
+                join(4);
                 tap("stages.3#0", CAT, w[0]);
             }
         }
@@ -396,6 +418,8 @@ int hh_net::finalize()
     }
     for (auto &g : graphs) hipGraphExecDestroy(g.exec);
     graphs.clear();
+    for (int l = 1; l < 4; ++l)
+        if (!lane_streams[l]) HH_CHECK_HIP(hipStreamCreateWithFlags(&lane_streams[l], hipStreamNonBlocking));
     finalized = true;
     return 0;
 }
@@ -454,10 +478,43 @@ static int pick_config(const ConvLayer &l, int Wo)
     return best;
 }
 
-int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *o2, hipStream_t s)
+int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *o2, hipStream_t s0)
 {
+    // Lanes: the resolution branches of an HR block and the outputs of a fusion layer are independent, so they run
+    // on separate HIP streams (forked from / joined to the caller's stream with events; the same calls become
+    // DAG edges under hipGraph capture).  The small low-resolution launches then fill CUs the big ones leave idle.
+    const bool multi = multi_lane && !taps_enabled && !prof_enabled;
+    hipStream_t L[4] = {s0, multi ? lane_streams[1] : s0, multi ? lane_streams[2] : s0, multi ? lane_streams[3] : s0};
+    lane_events_used = 0;
+    auto next_event = [&](hipEvent_t *e) -> int {
+        if (lane_events_used == lane_events.size()) {
+            hipEvent_t ne;
+            HH_CHECK_HIP(hipEventCreateWithFlags(&ne, getenv("HH_EVENT_DEFAULT") ? hipEventDefault : hipEventDisableTiming));
+            lane_events.push_back(ne);
+        }
+        *e = lane_events[lane_events_used++];
+        return 0;
+    };
+    int lanes_open = 1;  // lanes [0, lanes_open) have work that the caller's stream must wait for at the end
     for (const Op &op : ops) {
+        hipStream_t s = L[op.lane];
         switch (op.kind) {
+        case OP_JOIN: {
+            if (!multi) break;
+            // lanes that have not run anything yet only wait (recording on a stream that has not joined a
+            // capture and then waiting on that event from the capturing stream is illegal)
+            hipEvent_t e[4];
+            const int nrec = op.nlanes < lanes_open ? op.nlanes : lanes_open;
+            for (int l = 0; l < nrec; ++l) {
+                if (next_event(&e[l])) return 1;
+                HH_CHECK_HIP(hipEventRecord(e[l], L[l]));
+            }
+            for (int l = 0; l < op.nlanes; ++l)
+                for (int m = 0; m < nrec; ++m)
+                    if (m != l) HH_CHECK_HIP(hipStreamWaitEvent(L[l], e[m], 0));
+            if (op.nlanes > lanes_open) lanes_open = op.nlanes;
+            break;
+        }
         case OP_INCONVERT:
             HH_CHECK_HIP(launch_in_convert(images, tensors[op.out].ptr, B, H, W, s));
             break;
@@ -562,6 +619,13 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         }
         }
     }
+    if (multi)
+        for (int l = 1; l < lanes_open; ++l) {  // close the fork: the caller's stream waits for every lane
+            hipEvent_t e;
+            if (next_event(&e)) return 1;
+            HH_CHECK_HIP(hipEventRecord(e, L[l]));
+            HH_CHECK_HIP(hipStreamWaitEvent(s0, e, 0));
+        }
     return 0;
 }
 
@@ -571,14 +635,17 @@ int hh_net::forward(const float *images, int B, int H, int W, float *o1, float *
     if (B > rB || H > rH || W > rW || !tensors[0].ptr || (taps_enabled && !taps.empty() && !taps[0].copy))
         if (reserve(B, H, W)) return 1;
     lastB = B; lastH = H; lastW = W;
-    if (!use_graph || s == nullptr || taps_enabled || prof_enabled) return enqueue(images, B, H, W, o1, o2, s);
+    // hipGraph capture of the multi-stream fork/join segfaults inside the ROCm 7.2 runtime on this plan, so the
+    // multi-lane mode always launches eagerly (at B=32 eager and graph replay time identically); graphs remain
+    // available for single-lane execution (hh_set_multi_lane(net, 0)), which is what small batches want.
+    if (!use_graph || s == nullptr || taps_enabled || prof_enabled || multi_lane) return enqueue(images, B, H, W, o1, o2, s);
     for (auto &g : graphs)
         if (g.images == images && g.o1 == o1 && g.o2 == o2 && g.B == B && g.H == H && g.W == W) {
             HH_CHECK_HIP(hipGraphLaunch(g.exec, s));
             return 0;
         }
     hipGraph_t graph;
-    HH_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    HH_CHECK_HIP(hipStreamBeginCapture(s, getenv("HH_CAPTURE_MODE") ? (hipStreamCaptureMode)atoi(getenv("HH_CAPTURE_MODE")) : hipStreamCaptureModeThreadLocal));
     const int rc = enqueue(images, B, H, W, o1, o2, s);
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc) return rc;
@@ -586,7 +653,11 @@ int hh_net::forward(const float *images, int B, int H, int W, float *o1, float *
     GraphEntry g{images, o1, o2, B, H, W, nullptr};
     HH_CHECK_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
     hipGraphDestroy(graph);
-    if (graphs.size() >= 8) { hipGraphExecDestroy(graphs.front().exec); graphs.erase(graphs.begin()); }
+    if (graphs.size() >= 8) {  // evict the oldest entry; it may still be executing on this stream
+        HH_CHECK_HIP(hipStreamSynchronize(s));
+        hipGraphExecDestroy(graphs.front().exec);
+        graphs.erase(graphs.begin());
+    }
     graphs.push_back(g);
     HH_CHECK_HIP(hipGraphLaunch(g.exec, s));
     return 0;
@@ -616,6 +687,9 @@ hh_net::~hh_net()
 {
     release_workspace();
     for (auto &r : prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto &e : lane_events) hipEventDestroy(e);
+    for (int l = 1; l < 4; ++l)
+        if (lane_streams[l]) hipStreamDestroy(lane_streams[l]);
     for (auto &l : layers) {
         if (l.d_w) hipFree(l.d_w);
         if (l.d_bias) hipFree(l.d_bias);

@@ -43,7 +43,7 @@ struct TensorDesc {
     bool zero_init = false;
 };
 
-enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB };
+enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN };
 
 struct Op {
     OpKind kind = OP_CONV;
@@ -58,6 +58,8 @@ struct Op {
     int up[3] = {-1, -1, -1}, up_shift[3] = {0, 0, 0}, nup = 0;
     int C = 0;  // UPADD channel count / TAP channel count
     int tap = -1;
+    int lane = 0;     // execution lane (HIP stream): resolution branches / fusion outputs run concurrently
+    int nlanes = 0;   // OP_JOIN: all-to-all barrier over lanes [0, nlanes)
 };
 
 struct TapInfo {
@@ -99,6 +101,11 @@ struct hh_net {
     bool prof_enabled = false;
     std::vector<ProfRecord> prof;
     size_t prof_used = 0;
+    // lanes 1..3: internal streams forked from / joined to the caller's stream (also inside hipGraph capture)
+    hipStream_t lane_streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> lane_events;
+    size_t lane_events_used = 0;
+    bool multi_lane = true;
 
     int build();
     int add_param(const std::string &name, std::vector<int64_t> shape, bool counter = false);

@@ -82,8 +82,9 @@ class HigherHRNet(nn.Module):
     def workspace_bytes(self) -> int:
         return int(self._lib.hh_workspace_bytes(self._h))
 
-    def forward_raw(self, images: Tensor) -> tuple[Tensor, Tensor]:
-        """-> (init_heatmaps [B,2K,H/4,W/4], deconv_heatmaps [B,K,H/2,W/2]) fp32."""
+    def forward_raw(self, images: Tensor, out: tuple[Tensor, Tensor] | None = None) -> tuple[Tensor, Tensor]:
+        """-> (init_heatmaps [B,2K,H/4,W/4], deconv_heatmaps [B,K,H/2,W/2]) fp32.
+        `out` = preallocated result tensors (keeps the pointers, hence the cached hipGraph, stable)."""
         if self.training:
             raise NotImplementedError(
                 "HigherHRNet (MI355X engine): the training forward/backward (SURVEY.md §8 a20-a21) is not built "
@@ -97,8 +98,13 @@ class HigherHRNet(nn.Module):
         B, c, H, W = x.shape
         assert c == 3
         K = self.num_kpts
-        init = torch.empty((B, 2 * K, H // 4, W // 4), device=x.device, dtype=torch.float32)
-        dec = torch.empty((B, K, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        if out is not None:
+            init, dec = out
+            assert init.shape == (B, 2 * K, H // 4, W // 4) and dec.shape == (B, K, H // 2, W // 2)
+            assert init.is_contiguous() and dec.is_contiguous() and init.dtype == dec.dtype == torch.float32
+        else:
+            init = torch.empty((B, 2 * K, H // 4, W // 4), device=x.device, dtype=torch.float32)
+            dec = torch.empty((B, K, H // 2, W // 2), device=x.device, dtype=torch.float32)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
             _lib.check(self._lib.hh_forward(self._h, x.data_ptr(), B, H, W, init.data_ptr(), dec.data_ptr(),
