@@ -139,7 +139,7 @@ int hh_transform_coords(const float *xy_in, int n, double cx, double cy, double 
 // Kernel micro-benchmark (tools/conv_bench.py): one convolution shape, random bf16 data, `iters` back-to-back
 // launches of instantiation `cfg` timed with HIP events on `stream`.  Not part of the hot path.
 extern "C" int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, int cout, int with_res, int relu, int iters,
-                                   float *ms_per_launch)
+                                   float *ms_per_launch, unsigned long long *stamps16)
 {
     if (cfg < 0 || cfg >= conv_num_configs()) { hh_set_error("bad cfg"); return 1; }
     HH_CHECK_HIP(conv_init());
@@ -172,6 +172,10 @@ extern "C" int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, in
     p.Ho = Ho; p.Wo = Wo; p.cin = cin; p.cout_real = cout; p.cout_store = coutp; p.relu = relu;
     p.pad_y = p.pad_x = (c.KS - 1) / 2; p.B = B;
     p.tiles_x = (Wo + c.TW - 1) / c.TW; p.tiles_y = (Ho + c.th() - 1) / c.th(); p.ncg = coutp / c.cout_t();
+    unsigned long long *d_st = nullptr;
+    HH_CHECK_HIP(hipMalloc((void **)&d_st, 16 * 8));
+    HH_CHECK_HIP(hipMemset(d_st, 0, 16 * 8));
+    p.stamps = d_st;
     hipStream_t st;
     HH_CHECK_HIP(hipStreamCreate(&st));
     hipEvent_t e0, e1;
@@ -185,8 +189,9 @@ extern "C" int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, in
     float ms = 0;
     HH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_per_launch = ms / iters;
+    if (stamps16) HH_CHECK_HIP(hipMemcpy(stamps16, d_st, 16 * 8, hipMemcpyDeviceToHost));
     hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(st);
-    hipFree(d_in); hipFree(d_out); hipFree(d_res); hipFree(d_w); hipFree(d_bias);
+    hipFree(d_in); hipFree(d_out); hipFree(d_res); hipFree(d_w); hipFree(d_bias); hipFree(d_st);
     return 0;
 }
 

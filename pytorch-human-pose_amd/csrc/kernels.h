@@ -25,6 +25,7 @@ struct ConvParams {
     int relu;
     int pad_y, pad_x;     // top/left zero padding
     int B, tiles_x, tiles_y, ncg;
+    unsigned long long *stamps;  // diagnostic build (-DHH_STAMP) only
 };
 
 // Tile configuration of one kernel instantiation.
