@@ -81,7 +81,7 @@ int hh_conv_config(int cfg, int out[7]);
 /* Kernel micro-benchmark used by tools/conv_bench.py (not on the hot path): `iters` back-to-back launches of
  * convolution instantiation `cfg` on random bf16 data, HIP-event timed; returns ms per launch.        */
 int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, int cout, int with_res, int relu, int iters,
-                        float *ms_per_launch, unsigned long long *stamps16);
+                        float *ms_per_launch, unsigned long long *stamps16, int ref_cfg, float *max_diff);
 
 int hh_debug_bb_bench(int B, int H, int W, int iters, float *ms_per_launch, unsigned long long *stamps64);
 

@@ -137,61 +137,107 @@ int hh_transform_coords(const float *xy_in, int n, double cx, double cy, double 
 
 // ---------------------------------------------------------------------------------------------------
 // Kernel micro-benchmark (tools/conv_bench.py): one convolution shape, random bf16 data, `iters` back-to-back
-// launches of instantiation `cfg` timed with HIP events on `stream`.  Not part of the hot path.
+// launches of instantiation `cfg` (>= HH_CFG_DMA_BASE: LDS-DMA variant) timed with HIP events.  If `max_diff`
+// is given, the output is also compared with generic instantiation `ref_cfg` on the same data.  Not on the hot path.
 extern "C" int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, int cout, int with_res, int relu, int iters,
-                                   float *ms_per_launch, unsigned long long *stamps16)
+                                   float *ms_per_launch, unsigned long long *stamps16, int ref_cfg, float *max_diff)
 {
-    if (cfg < 0 || cfg >= conv_num_configs()) { hh_set_error("bad cfg"); return 1; }
     HH_CHECK_HIP(conv_init());
-    const ConvConfig &c = conv_config(cfg);
+#ifdef HH_EXPERIMENTAL
+    HH_CHECK_HIP(conv_dma_init());
+#else
+    if (cfg >= HH_CFG_DMA_BASE || ref_cfg >= HH_CFG_DMA_BASE) { hh_set_error("LDS-DMA variants need a `make EXPERIMENTAL=1` build"); return 1; }
+#endif
+    const bool is_dma = cfg >= HH_CFG_DMA_BASE;
+    if (!is_dma && (cfg < 0 || cfg >= conv_num_configs())) { hh_set_error("bad cfg"); return 1; }
+#ifdef HH_EXPERIMENTAL
+    if (is_dma && cfg - HH_CFG_DMA_BASE >= conv_dma_num_variants()) { hh_set_error("bad dma variant"); return 1; }
+#endif
+    ConvConfig c = is_dma ? ConvConfig{3, 1, 16, 2, 1, 1, 32} : conv_config(cfg);
     if (cin % c.KC) { hh_set_error("cin must be a multiple of the config's KC"); return 1; }
     const int coutp = (cout + c.cout_t() - 1) / c.cout_t() * c.cout_t();
     const int Ho = c.S == 2 ? Hin / 2 : Hin, Wo = c.S == 2 ? Win / 2 : Win;
     const size_t n_in = (size_t)B * Hin * Win * cin, n_out = (size_t)B * Ho * Wo * coutp;
-    const size_t n_w = (size_t)coutp * cin * c.KS * c.KS;
-    std::vector<bf16_raw> h_in(n_in), h_w(n_w);
+    std::vector<bf16_raw> h_in(n_in), h_res(n_out);
+    std::vector<float> W((size_t)cout * cin * c.KS * c.KS), scale(coutp, 1.f);
     uint32_t s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (bf16_raw)(0x3c00u + ((s >> 16) & 0x1ffu) + ((s >> 30) << 15)); };
+    auto rndf = [&]() { s = s * 1664525u + 1013904223u; return ((int)(s >> 20) - 2048) / 16384.0f; };
     for (auto &v : h_in) v = rnd();
-    for (auto &v : h_w) v = rnd();
-    bf16_raw *d_in, *d_out, *d_res, *d_w;
+    for (auto &v : h_res) v = rnd();
+    for (auto &v : W) v = rndf();
+    bf16_raw *d_in, *d_out, *d_out2, *d_res, *d_zero;
     float *d_bias;
     HH_CHECK_HIP(hipMalloc((void **)&d_in, n_in * 2));
     HH_CHECK_HIP(hipMalloc((void **)&d_out, n_out * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_out2, n_out * 2));
     HH_CHECK_HIP(hipMalloc((void **)&d_res, n_out * 2));
-    HH_CHECK_HIP(hipMalloc((void **)&d_w, n_w * 2));
     HH_CHECK_HIP(hipMalloc((void **)&d_bias, (size_t)coutp * 4));
+    HH_CHECK_HIP(hipMalloc((void **)&d_zero, 256));
     HH_CHECK_HIP(hipMemcpy(d_in, h_in.data(), n_in * 2, hipMemcpyHostToDevice));
-    HH_CHECK_HIP(hipMemcpy(d_w, h_w.data(), n_w * 2, hipMemcpyHostToDevice));
-    HH_CHECK_HIP(hipMemset(d_res, 0, n_out * 2));
+    HH_CHECK_HIP(hipMemcpy(d_res, h_res.data(), n_out * 2, hipMemcpyHostToDevice));
     HH_CHECK_HIP(hipMemset(d_bias, 0, (size_t)coutp * 4));
-    ConvParams p{};
-    p.in = d_in; p.in_cs = cin; p.Hin = Hin; p.Win = Win; p.w = d_w; p.bias = d_bias;
-    p.res = with_res ? d_res : nullptr; p.res_cs = coutp;
-    p.out = d_out; p.out_cs = coutp; p.Hob = Ho; p.Wob = Wo; p.osy = p.osx = 1;
-    p.Ho = Ho; p.Wo = Wo; p.cin = cin; p.cout_real = cout; p.cout_store = coutp; p.relu = relu;
-    p.pad_y = p.pad_x = (c.KS - 1) / 2; p.B = B;
-    p.tiles_x = (Wo + c.TW - 1) / c.TW; p.tiles_y = (Ho + c.th() - 1) / c.th(); p.ncg = coutp / c.cout_t();
+    HH_CHECK_HIP(hipMemset(d_zero, 0, 256));
+    HH_CHECK_HIP(hipMemset(d_out, 0, n_out * 2));
+    HH_CHECK_HIP(hipMemset(d_out2, 0, n_out * 2));
     unsigned long long *d_st = nullptr;
     HH_CHECK_HIP(hipMalloc((void **)&d_st, 16 * 8));
     HH_CHECK_HIP(hipMemset(d_st, 0, 16 * 8));
-    p.stamps = d_st;
     hipStream_t st;
     HH_CHECK_HIP(hipStreamCreate(&st));
-    hipEvent_t e0, e1;
-    HH_CHECK_HIP(hipEventCreate(&e0));
-    HH_CHECK_HIP(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) HH_CHECK_HIP(conv_launch(cfg, p, st));
-    HH_CHECK_HIP(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) HH_CHECK_HIP(conv_launch(cfg, p, st));
-    HH_CHECK_HIP(hipEventRecord(e1, st));
-    HH_CHECK_HIP(hipEventSynchronize(e1));
-    float ms = 0;
-    HH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *ms_per_launch = ms / iters;
+    auto run = [&](int k, bf16_raw *out, int n, float *ms_out) -> int {
+        const bool dma = k >= HH_CFG_DMA_BASE;
+        const ConvConfig cc = dma ? ConvConfig{3, 1, 16, 2, 1, 1, 32} : conv_config(k);
+        std::vector<bf16_raw> packed;
+        hh_pack_weights(W.data(), scale.data(), cc.KS, cin, cout, cc.KC, cc.cout_t(), false, 0, 0, packed);
+        bf16_raw *d_w;
+        HH_CHECK_HIP(hipMalloc((void **)&d_w, packed.size() * 2));
+        HH_CHECK_HIP(hipMemcpy(d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+        ConvParams p{};
+        p.in = d_in; p.in_cs = cin; p.Hin = Hin; p.Win = Win; p.w = d_w; p.bias = d_bias;
+        p.res = with_res ? d_res : nullptr; p.res_cs = coutp;
+        p.out = out; p.out_cs = coutp; p.Hob = Ho; p.Wob = Wo; p.osy = p.osx = 1;
+        p.Ho = Ho; p.Wo = Wo; p.cin = cin; p.cout_real = cout; p.cout_store = coutp; p.relu = relu;
+        p.pad_y = p.pad_x = (cc.KS - 1) / 2; p.B = B; p.zero = d_zero; p.stamps = d_st;
+        p.tiles_x = (Wo + cc.TW - 1) / cc.TW; p.tiles_y = (Ho + cc.th() - 1) / cc.th(); p.ncg = coutp / cc.cout_t();
+#ifdef HH_EXPERIMENTAL
+        auto launch = [&]() { return dma ? conv_dma_launch(k - HH_CFG_DMA_BASE, p, st) : conv_launch(k, p, st); };
+#else
+        auto launch = [&]() { return conv_launch(k, p, st); };
+#endif
+        hipEvent_t e0, e1;
+        HH_CHECK_HIP(hipEventCreate(&e0));
+        HH_CHECK_HIP(hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) HH_CHECK_HIP(launch());
+        HH_CHECK_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < n; ++i) HH_CHECK_HIP(launch());
+        HH_CHECK_HIP(hipEventRecord(e1, st));
+        HH_CHECK_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        HH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (ms_out) *ms_out = ms / n;
+        hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d_w);
+        return 0;
+    };
+    if (run(cfg, d_out, iters, ms_per_launch)) return 1;
     if (stamps16) HH_CHECK_HIP(hipMemcpy(stamps16, d_st, 16 * 8, hipMemcpyDeviceToHost));
-    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(st);
-    hipFree(d_in); hipFree(d_out); hipFree(d_res); hipFree(d_w); hipFree(d_bias); hipFree(d_st);
+    if (max_diff) {
+        if (run(ref_cfg, d_out2, 1, nullptr)) return 1;
+        std::vector<bf16_raw> a(n_out), b2(n_out);
+        HH_CHECK_HIP(hipMemcpy(a.data(), d_out, n_out * 2, hipMemcpyDeviceToHost));
+        HH_CHECK_HIP(hipMemcpy(b2.data(), d_out2, n_out * 2, hipMemcpyDeviceToHost));
+        float md = 0.f;
+        for (size_t i = 0; i < n_out; ++i) {
+            uint32_t ua = (uint32_t)a[i] << 16, ub = (uint32_t)b2[i] << 16;
+            float fa, fb;
+            memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
+            const float d = fa > fb ? fa - fb : fb - fa;
+            if (d > md || d != d) md = d;
+        }
+        *max_diff = md;
+    }
+    hipStreamDestroy(st);
+    hipFree(d_in); hipFree(d_out); hipFree(d_out2); hipFree(d_res); hipFree(d_bias); hipFree(d_st); hipFree(d_zero);
     return 0;
 }
 

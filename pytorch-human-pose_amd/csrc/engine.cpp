@@ -336,6 +336,35 @@ int hh_net::build()
     return 0;
 }
 
+// Kernel-order weight image: [cout_group][cin_chunk][tap][KC/8][COUT_T][8] bf16, BN scale folded in, zero padded.
+void hh_pack_weights(const float *W, const float *scale, int ks, int cin, int cout, int KC, int COUT_T, bool transposed,
+                     int py, int px, std::vector<bf16_raw> &packed)
+{
+    const int coutp = round_up(cout, COUT_T), ncg = coutp / COUT_T, cin_pad = round_up(cin, KC);
+    const int nch = cin_pad / KC, taps = ks * ks, C8 = KC / 8;
+    packed.assign((size_t)ncg * nch * taps * C8 * COUT_T * 8, 0);
+    size_t o = 0;
+    for (int cg = 0; cg < ncg; ++cg)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int t = 0; t < taps; ++t) {
+                int ky = t / ks, kx = t % ks;
+                if (transposed) {  // patch row 0/1 of phase py <-> ky of the 4x4 stride-2 transposed conv
+                    ky = py == 0 ? (ky == 0 ? 3 : 1) : (ky == 0 ? 2 : 0);
+                    kx = px == 0 ? (kx == 0 ? 3 : 1) : (kx == 0 ? 2 : 0);
+                }
+                for (int c8 = 0; c8 < C8; ++c8)
+                    for (int ci_o = 0; ci_o < COUT_T; ++ci_o)
+                        for (int j = 0; j < 8; ++j, ++o) {
+                            const int co = cg * COUT_T + ci_o, ci = ch * KC + c8 * 8 + j;
+                            if (co >= cout || ci >= cin) continue;
+                            float v;
+                            if (transposed) v = W[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+                            else v = W[(((size_t)co * cin + ci) * ks + ky) * ks + kx];
+                            packed[o] = f2bf(v * scale[co]);
+                        }
+            }
+}
+
 // ------------------------------------------------------------------------- finalize
 static int family_pick(int ks, int stride, int cin_pad, int coutp, int *KC, int *NT)
 {
@@ -388,27 +417,8 @@ int hh_net::finalize()
                 shift[co] = l.bias.empty() ? 0.f : get(l.bias)[co];
             }
         }
-        std::vector<bf16_raw> packed((size_t)l.ncg * nch * taps * C8 * COUT_T * 8, 0);
-        size_t o = 0;
-        for (int cg = 0; cg < l.ncg; ++cg)
-            for (int ch = 0; ch < nch; ++ch)
-                for (int t = 0; t < taps; ++t) {
-                    int ky = t / l.ks, kx = t % l.ks;
-                    if (l.transposed) {  // patch row 0/1 of phase py <-> ky (see conv_mfma.hip header / DESIGN.md)
-                        ky = l.py == 0 ? (ky == 0 ? 3 : 1) : (ky == 0 ? 2 : 0);
-                        kx = l.px == 0 ? (kx == 0 ? 3 : 1) : (kx == 0 ? 2 : 0);
-                    }
-                    for (int c8 = 0; c8 < C8; ++c8)
-                        for (int ci_o = 0; ci_o < COUT_T; ++ci_o)
-                            for (int j = 0; j < 8; ++j, ++o) {
-                                const int co = cg * COUT_T + ci_o, ci = ch * l.KC + c8 * 8 + j;
-                                if (co >= l.cout || ci >= l.cin) continue;
-                                float v;
-                                if (l.transposed) v = W[(((size_t)ci * l.cout + co) * 4 + ky) * 4 + kx];
-                                else v = W[(((size_t)co * l.cin + ci) * l.ks + ky) * l.ks + kx];
-                                packed[o] = f2bf(v * scale[co]);
-                            }
-                }
+        std::vector<bf16_raw> packed;
+        hh_pack_weights(W.data(), scale.data(), l.ks, l.cin, l.cout, l.KC, COUT_T, l.transposed, l.py, l.px, packed);
         if (l.d_w) { hipFree(l.d_w); l.d_w = nullptr; }
         if (l.d_bias) { hipFree(l.d_bias); l.d_bias = nullptr; }
         HH_CHECK_HIP(hipMalloc((void **)&l.d_w, packed.size() * 2));

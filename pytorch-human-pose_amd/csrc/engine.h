@@ -9,6 +9,8 @@
 #include "kernels.h"
 
 void hh_set_error(const std::string &msg);
+void hh_pack_weights(const float *W, const float *scale, int ks, int cin, int cout, int KC, int COUT_T, bool transposed,
+                     int py, int px, std::vector<unsigned short> &packed);
 #define HH_CHECK_HIP(expr)                                                                             \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \

@@ -26,6 +26,7 @@ struct ConvParams {
     int pad_y, pad_x;     // top/left zero padding
     int B, tiles_x, tiles_y, ncg;
     unsigned long long *stamps;  // diagnostic build (-DHH_STAMP) only
+    const bf16_raw *zero;        // >= 16 zero bytes (16-B aligned): DMA source of out-of-image pixels (conv3x3_dma.hip)
 };
 
 // Tile configuration of one kernel instantiation.
@@ -46,6 +47,13 @@ const ConvConfig &conv_config(int i);
 // Launches config `cfg_index`; the grid is B*tiles_y*tiles_x*ncg blocks of 256 threads.
 hipError_t conv_launch(int cfg_index, const ConvParams &p, hipStream_t stream);
 hipError_t conv_init();  // raises the dynamic-LDS limit of every instantiation
+
+// LDS-DMA 3x3 stride-1 kernel for the 64..256-channel branches (conv3x3_dma.hip); weights packed with KC=16, COUT_T=64.
+#define HH_CFG_DMA_BASE 200
+int conv_dma_num_variants();
+void conv_dma_variant(int v, int *PT, int *TW);
+hipError_t conv_dma_init();
+hipError_t conv_dma_launch(int variant, ConvParams p, hipStream_t s);
 
 // Fused 32-channel BasicBlock (basicblock_fused.hip): out = relu(conv2(relu(conv1(in))) + in), BN folded.
 struct BBParams {
