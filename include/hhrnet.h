@@ -36,6 +36,12 @@ const char *hh_last_error(void);
 hh_net *hh_create(int num_kpts, int C, int dtype);
 void hh_destroy(hh_net *net);
 
+/* ClassificationHRNet(C, num_classes) -- classification/architectures/hrnet.py:64-74 (BASELINE.json configs[0]):
+ * the same backbone with a 4-scale last fusion + ClassificationHead.  Parameters/keys as the reference's
+ * state dict (hh_num_params/hh_load_weights/hh_finalize work on the handle); forward writes logits [B,num_classes]. */
+hh_net *hh_create_classifier(int C, int num_classes, int dtype);
+int hh_forward_classifier(hh_net *net, const float *images, int B, int H, int W, float *logits, void *stream);
+
 /* state_dict() introspection: key names and shapes in the reference's order. */
 int hh_num_params(const hh_net *net);
 const char *hh_param_name(const hh_net *net, int index);

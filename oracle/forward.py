@@ -140,6 +140,24 @@ def higher_hrnet(images: torch.Tensor, sd: dict, num_kpts: int = 17, return_taps
     return (hms, tags, taps) if return_taps else (hms, tags)
 
 
+def classification_hrnet(images: torch.Tensor, sd: dict) -> torch.Tensor:
+    """ClassificationHRNet.forward (/root/reference/src/classification/architectures/hrnet.py:48-74): 4-scale backbone,
+    one Bottleneck per scale (C_i -> 128/256/512/1024), stride-2 conv(+bias)+BN+ReLU downsample-and-add chain,
+    1x1 -> 2048 + BN + ReLU, global average pool, Linear."""
+    p = _SD(sd)
+    xs, _ = backbone(images, p.sub("backbone"), single_scale_out=False)
+    hp = p.sub("classification_head")
+    out = bottleneck(xs[0], hp.sub("chann_incr_blocks.0"))
+    for i in range(3):
+        d = hp.sub(f"downsample_blocks.{i}")
+        down = F.relu(_bn(F.conv2d(out, d["0.weight"], d["0.bias"], 2, 1), d.sub("1")))
+        out = bottleneck(xs[i + 1], hp.sub(f"chann_incr_blocks.{i + 1}")) + down
+    f = hp.sub("final_conv")
+    out = F.relu(_bn(F.conv2d(out, f["0.weight"], f["0.bias"]), f.sub("1")))
+    flat = F.avg_pool2d(out, kernel_size=out.shape[2:]).view(out.shape[0], -1)
+    return F.linear(flat, hp["classifier.weight"], hp["classifier.bias"])
+
+
 COCO_FLIP_INDEX = [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15]  # keypoints/transforms.py:11
 
 

@@ -36,6 +36,8 @@ def _sig(lib):
         "hh_last_error": (cp, []),
         "hh_create": (vp, [i32, i32, i32]),
         "hh_destroy": (None, [vp]),
+        "hh_create_classifier": (vp, [i32, i32, i32]),
+        "hh_forward_classifier": (i32, [vp, vp, i32, i32, i32, vp, vp]),
         "hh_num_params": (i32, [vp]),
         "hh_param_name": (cp, [vp, i32]),
         "hh_param_shape": (i32, [vp, i32, pi64]),

@@ -22,6 +22,22 @@ hh_net *hh_create(int num_kpts, int C, int dtype)
     n->build();
     return n;
 }
+hh_net *hh_create_classifier(int C, int num_classes, int dtype)
+{
+    if (dtype != HH_DTYPE_BF16) { hh_set_error("hh_create_classifier: only HH_DTYPE_BF16 is implemented"); return nullptr; }
+    if (C <= 0 || C % 16 || num_classes <= 0) { hh_set_error("hh_create_classifier: need C % 16 == 0 and num_classes > 0"); return nullptr; }
+    hh_net *n = new hh_net();
+    n->K = 17; n->C = C; n->dtype = dtype; n->kind = 1; n->num_classes = num_classes;
+    n->build();
+    return n;
+}
+int hh_forward_classifier(hh_net *net, const float *images, int B, int H, int W, float *logits, void *stream)
+{
+    if (!net || net->kind != 1) { hh_set_error("hh_forward_classifier: not a classifier handle"); return 1; }
+    if (!images || !logits) { hh_set_error("hh_forward_classifier: null buffer"); return 1; }
+    if (B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) { hh_set_error("hh_forward_classifier: H and W must be positive multiples of 32"); return 1; }
+    return net->forward(images, B, H, W, logits, nullptr, 0, (hipStream_t)stream);
+}
 void hh_destroy(hh_net *net) { delete net; }
 
 int hh_num_params(const hh_net *net) { return (int)net->params.size(); }
@@ -58,6 +74,7 @@ int64_t hh_workspace_bytes(const hh_net *net) { return net->ws_bytes; }
 int hh_forward(hh_net *net, const float *images, int B, int H, int W, float *init_heatmaps, float *deconv_heatmaps,
                int use_graph, void *stream)
 {
+    if (net->kind != 0) { hh_set_error("hh_forward: classifier handle, use hh_forward_classifier"); return 1; }
     if (!images || !init_heatmaps || !deconv_heatmaps) { hh_set_error("hh_forward: null buffer"); return 1; }
     if (B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) { hh_set_error("hh_forward: H and W must be positive multiples of 32"); return 1; }
     return net->forward(images, B, H, W, init_heatmaps, deconv_heatmaps, use_graph, (hipStream_t)stream);

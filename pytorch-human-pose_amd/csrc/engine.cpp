@@ -98,7 +98,7 @@ struct Builder {
                 if (s > 0) {
                     const std::string fp = sp + ".blocks." + std::to_string(2 * b + 1);
                     const bool last = s == 3 && b == nblocks[s] - 1;
-                    const int nout = last ? 1 : nsc;
+                    const int nout = (last && n.kind == 0) ? 1 : nsc;  // final_stage_single_scale (hrnet.py:314-318)
                     for (int i = 0; i < nout; ++i)
                         for (int j = 0; j < nsc; ++j) {
                             const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
@@ -122,6 +122,26 @@ struct Builder {
                     p_conv(q + ".0", w[nsc - 1], w[nsc], 3); p_bn(q + ".1", w[nsc]);
                 }
             }
+        }
+        if (n.kind == 1) {  // ClassificationHead (classification/architectures/hrnet.py:7-46)
+            const int outs[4] = {128, 256, 512, 1024};
+            const std::string hp = "classification_head";
+            for (int i = 0; i < 4; ++i) {
+                const std::string up = hp + ".chann_incr_blocks." + std::to_string(i);
+                const int mid = outs[i] / 4;
+                p_conv(up + ".conv1", w[i], mid, 1); p_bn(up + ".bn1", mid);
+                p_conv(up + ".conv2", mid, mid, 3); p_bn(up + ".bn2", mid);
+                p_conv(up + ".conv3", mid, outs[i], 1); p_bn(up + ".bn3", outs[i]);
+                if (w[i] != outs[i]) { p_conv(up + ".downsample.0", w[i], outs[i], 1); p_bn(up + ".downsample.1", outs[i]); }
+            }
+            for (int i = 0; i < 3; ++i) {
+                const std::string dpn = hp + ".downsample_blocks." + std::to_string(i);
+                p_conv(dpn + ".0", outs[i], outs[i + 1], 3, true); p_bn(dpn + ".1", outs[i + 1]);
+            }
+            p_conv(hp + ".final_conv.0", 1024, 2048, 1, true); p_bn(hp + ".final_conv.1", 2048);
+            n.add_param(hp + ".classifier.weight", {n.num_classes, 2048});
+            n.add_param(hp + ".classifier.bias", {n.num_classes});
+            return;
         }
         p_conv("init_heatmaps_head", C, 2 * K, 1, true);
         const std::string dp = "deconv_layers.0";
@@ -255,7 +275,7 @@ struct Builder {
                     tap("stages." + std::to_string(s) + ".blocks." + std::to_string(2 * b) + "#" + std::to_string(i), x[i], w[i]);
                 // FusionLayer (hrnet.py:166-229)
                 const std::string fp = sp + ".blocks." + std::to_string(2 * b + 1);
-                const bool last = s == 3 && b == nblocks[s] - 1;
+                const bool last = s == 3 && b == nblocks[s] - 1 && n.kind == 0;  // HigherHRNet keeps one scale
                 const int nout = last ? 1 : nsc;
                 for (int i = 0; i < nout; ++i) {
                     lane = i;  // output i only writes its own tensors; it feeds branch i of the next block directly
@@ -299,8 +319,36 @@ struct Builder {
                 for (int i = 0; i <= nsc; ++i) tap("stages." + std::to_string(s) + "#" + std::to_string(i), x[i], w[i]);
             } else {
                 join(4);
-                tap("stages.3#0", CAT, w[0]);
+                if (n.kind == 0) tap("stages.3#0", CAT, w[0]);
             }
+        }
+        if (n.kind == 1) {  // ClassificationHead.forward (classification/architectures/hrnet.py:48-61)
+            const int outs[4] = {128, 256, 512, 1024};
+            const std::string hp = "classification_head";
+            int cur = -1;
+            for (int i = 0; i < 4; ++i) {
+                const std::string up = hp + ".chann_incr_blocks." + std::to_string(i);
+                const int mid = outs[i] / 4, sh = 2 + i;
+                const int a1 = T(mid, sh), a2 = T(mid, sh), Dn = T(outs[i], sh), Yn = T(outs[i], sh);
+                cb(up, "conv1", "bn1", w[i], mid, 1, 1, x[i], a1, 1);
+                cb(up, "conv2", "bn2", mid, mid, 3, 1, a1, a2, 1);
+                cb(up, "downsample.0", "downsample.1", w[i], outs[i], 1, 1, x[i], Dn, 0);
+                cb(up, "conv3", "bn3", mid, outs[i], 1, 1, a2, Yn, 1, Dn);
+                if (i == 0) { cur = Yn; continue; }
+                const std::string dpn = hp + ".downsample_blocks." + std::to_string(i - 1);
+                const int dw = T(outs[i], sh);
+                conv(L(dpn + ".0", dpn + ".1", outs[i - 1], outs[i], 3, 2, dpn + ".0.bias"), cur, dw, 1);
+                Op add;  // out = bottleneck(x_i) + downsampled, no activation
+                add.kind = OP_UPADD; add.in = Yn; add.out = Yn; add.C = outs[i]; add.relu = 0;
+                add.up[0] = dw; add.up_shift[0] = 0; add.nup = 1;
+                n.ops.push_back(add);
+                cur = Yn;
+            }
+            const int FC = T(2048, 5);
+            conv(L(hp + ".final_conv.0", hp + ".final_conv.1", 1024, 2048, 1, 1, hp + ".final_conv.0.bias"), cur, FC, 1);
+            { Op o; o.kind = OP_AVGPOOL; o.in = FC; o.C = 2048; n.ops.push_back(o); }
+            { Op o; o.kind = OP_LINEAR; n.ops.push_back(o); }
+            return;
         }
 
         // heads (higher_hrnet.py:52,70-79): 1x1 conv with bias -> fp32 NCHW result AND bf16 copy into CAT
@@ -410,8 +458,9 @@ int hh_net::finalize()
                 const float g = get(l.bn + ".weight")[co], bta = get(l.bn + ".bias")[co];
                 const float mu = get(l.bn + ".running_mean")[co], var = get(l.bn + ".running_var")[co];
                 const float sc = g / std::sqrt(var + 1e-5f);
+                const float cb = l.bias.empty() ? 0.f : get(l.bias)[co];  // conv bias in front of BN (classification head)
                 scale[co] = sc;
-                shift[co] = bta - mu * sc;
+                shift[co] = bta + (cb - mu) * sc;
             } else {
                 scale[co] = 1.f;
                 shift[co] = l.bias.empty() ? 0.f : get(l.bias)[co];
@@ -425,6 +474,16 @@ int hh_net::finalize()
         HH_CHECK_HIP(hipMalloc((void **)&l.d_bias, (size_t)coutp * 4));
         HH_CHECK_HIP(hipMemcpy(l.d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
         HH_CHECK_HIP(hipMemcpy(l.d_bias, shift.data(), (size_t)coutp * 4, hipMemcpyHostToDevice));
+    }
+    if (kind == 1) {
+        const auto &fw = get("classification_head.classifier.weight");
+        const auto &fb = get("classification_head.classifier.bias");
+        if (d_fc_w) hipFree(d_fc_w);
+        if (d_fc_b) hipFree(d_fc_b);
+        HH_CHECK_HIP(hipMalloc((void **)&d_fc_w, fw.size() * 4));
+        HH_CHECK_HIP(hipMalloc((void **)&d_fc_b, fb.size() * 4));
+        HH_CHECK_HIP(hipMemcpy(d_fc_w, fw.data(), fw.size() * 4, hipMemcpyHostToDevice));
+        HH_CHECK_HIP(hipMemcpy(d_fc_b, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
     }
     for (auto &g : graphs) hipGraphExecDestroy(g.exec);
     graphs.clear();
@@ -549,6 +608,19 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                                         hipMemcpyDeviceToDevice, s));
             break;
         }
+        case OP_AVGPOOL: {
+            const TensorDesc &ti = tensors[op.in];
+            if (pool_cap < B * op.C) {
+                if (d_pool) hipFree(d_pool);
+                HH_CHECK_HIP(hipMalloc((void **)&d_pool, (size_t)B * op.C * 4));
+                pool_cap = B * op.C;
+            }
+            HH_CHECK_HIP(launch_avgpool(ti.ptr, ti.C, d_pool, B, (H >> ti.shift) * (W >> ti.shift), op.C, s));
+            break;
+        }
+        case OP_LINEAR:
+            HH_CHECK_HIP(launch_linear(d_pool, d_fc_w, d_fc_b, o1, B, 2048, num_classes, s));
+            break;
         case OP_BB: {
             const ConvLayer &l1 = layers[op.layer], &l2 = layers[op.layer2];
             const TensorDesc &ti = tensors[op.in], &to = tensors[op.out];
@@ -690,6 +762,7 @@ double hh_net::flops(int B, int H, int W) const
         // a transposed-conv phase: every input pixel meets 4 of the 16 taps per phase (16 over the 4 phases)
         macs += ho * wo * (double)l.cin * l.cout * l.ks * l.ks;
     }
+    if (kind == 1) macs += 2048.0 * num_classes;
     return 2.0 * macs * B;
 }
 
@@ -697,6 +770,9 @@ hh_net::~hh_net()
 {
     release_workspace();
     for (auto &r : prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    if (d_pool) hipFree(d_pool);
+    if (d_fc_w) hipFree(d_fc_w);
+    if (d_fc_b) hipFree(d_fc_b);
     for (auto &e : lane_events) hipEventDestroy(e);
     for (int l = 1; l < 4; ++l)
         if (lane_streams[l]) hipStreamDestroy(lane_streams[l]);

@@ -45,7 +45,7 @@ struct TensorDesc {
     bool zero_init = false;
 };
 
-enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN };
+enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR };
 
 struct Op {
     OpKind kind = OP_CONV;
@@ -85,6 +85,10 @@ struct GraphEntry {
 
 struct hh_net {
     int K, C, dtype;
+    int kind = 0;          // 0 = HigherHRNet, 1 = ClassificationHRNet (classification/architectures/hrnet.py)
+    int num_classes = 0;
+    float *d_pool = nullptr, *d_fc_w = nullptr, *d_fc_b = nullptr;  // classifier: pooled features [B,2048], Linear params (fp32)
+    int pool_cap = 0;
     std::vector<ParamSlot> params;
     std::map<std::string, int> param_index;
     std::vector<ConvLayer> layers;

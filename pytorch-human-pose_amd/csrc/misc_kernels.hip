@@ -129,3 +129,42 @@ hipError_t launch_flip_merge(float *hm, int64_t hm_bs, const float *hmf, int64_t
                        B, K, h, w);
     return hipGetLastError();
 }
+
+// F.avg_pool2d over the whole map (classification/architectures/hrnet.py:57): one thread = 8 channels of one image
+__global__ __launch_bounds__(256) void avgpool_kernel(const bf16_raw *__restrict__ in, int in_cs, float *__restrict__ out, int B,
+                                                      int HW, int C)
+{
+    const int c8n = C / 8, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * c8n) return;
+    const int b = i / c8n, c8 = i % c8n;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < HW; ++p) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + ((size_t)b * HW + p) * in_cs + c8 * 8);
+        acc[0] += lo(v.x); acc[1] += hi(v.x); acc[2] += lo(v.y); acc[3] += hi(v.y);
+        acc[4] += lo(v.z); acc[5] += hi(v.z); acc[6] += lo(v.w); acc[7] += hi(v.w);
+    }
+    for (int k = 0; k < 8; ++k) out[(size_t)b * C + c8 * 8 + k] = acc[k] / (float)HW;
+}
+hipError_t launch_avgpool(const bf16_raw *in, int in_cs, float *out, int B, int HW, int C, hipStream_t s)
+{
+    hipLaunchKernelGGL(avgpool_kernel, dim3((B * (C / 8) + 255) / 256), dim3(256), 0, s, in, in_cs, out, B, HW, C);
+    return hipGetLastError();
+}
+
+// nn.Linear (classification/architectures/hrnet.py:46,60): one wave per output feature, fp32
+__global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                     const float *__restrict__ bias, float *__restrict__ y, int K, int N)
+{
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc += x[(size_t)b * K + k] * w[(size_t)n * K + k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) y[(size_t)b * N + n] = acc + bias[n];
+}
+hipError_t launch_linear(const float *x, const float *w, const float *bias, float *y, int B, int K, int N, hipStream_t s)
+{
+    hipLaunchKernelGGL(linear_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, x, w, bias, y, K, N);
+    return hipGetLastError();
+}

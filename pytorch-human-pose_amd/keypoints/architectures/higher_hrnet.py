@@ -22,9 +22,9 @@ from .spec import attach_modules, higher_hrnet_rows
 class _NetHandle:
     """Owns the hh_net* so the nn.Module needs no __del__ of its own."""
 
-    def __init__(self, lib, num_kpts: int, C: int):
+    def __init__(self, lib, ptr):
         self.lib = lib
-        self.ptr = lib.hh_create(num_kpts, C, 1)
+        self.ptr = ptr
         if not self.ptr:
             raise _lib.HHError(lib.hh_last_error().decode())
 
@@ -34,15 +34,13 @@ class _NetHandle:
             self.lib.hh_destroy(ptr)
 
 
-class HigherHRNet(nn.Module):
-    def __init__(self, num_kpts: int, C: int = 32):
-        super().__init__()
-        self.num_kpts = num_kpts
-        self.C = C
-        self.num_deconv_layers = 1
-        attach_modules(self, higher_hrnet_rows(num_kpts, C))
+class EngineModule(nn.Module):
+    """nn.Module whose parameters live under the reference's state-dict keys and whose forward runs in the HIP engine."""
+
+    def _init_engine(self, rows, create) -> None:
+        attach_modules(self, rows)
         self._lib = _lib.load()
-        self._handle = _NetHandle(self._lib, num_kpts, C)
+        self._handle = _NetHandle(self._lib, create(self._lib))
         self._h = self._handle.ptr
         self._dirty = True
         self.use_graph = True
@@ -82,21 +80,48 @@ class HigherHRNet(nn.Module):
     def workspace_bytes(self) -> int:
         return int(self._lib.hh_workspace_bytes(self._h))
 
-    def forward_raw(self, images: Tensor, out: tuple[Tensor, Tensor] | None = None) -> tuple[Tensor, Tensor]:
-        """-> (init_heatmaps [B,2K,H/4,W/4], deconv_heatmaps [B,K,H/2,W/2]) fp32.
-        `out` = preallocated result tensors (keeps the pointers, hence the cached hipGraph, stable)."""
+    def _check_input(self, images: Tensor) -> Tensor:
         if self.training:
             raise NotImplementedError(
-                "HigherHRNet (MI355X engine): the training forward/backward (SURVEY.md §8 a20-a21) is not built "
-                "yet; call .eval() for inference"
+                f"{type(self).__name__} (MI355X engine): the training forward/backward (SURVEY.md §8 a20-a21) is not "
+                "built yet; call .eval() for inference"
             )
         if not images.is_cuda:
-            raise _lib.HHError("HigherHRNet forward needs a CUDA/HIP tensor: there is no CPU path")
+            raise _lib.HHError(f"{type(self).__name__} forward needs a CUDA/HIP tensor: there is no CPU path")
         if self._dirty:
             self.sync_weights()
         x = images.contiguous().float()
-        B, c, H, W = x.shape
-        assert c == 3
+        assert x.dim() == 4 and x.shape[1] == 3
+        return x
+
+    # ---- debug taps for the parity tests
+    def set_taps(self, enable: bool) -> None:
+        self._lib.hh_set_taps(self._h, int(enable))
+
+    def read_taps(self) -> dict[str, np.ndarray]:
+        out = {}
+        for i in range(self._lib.hh_num_taps(self._h)):
+            shape = (C.c_int64 * 4)()
+            _lib.check(self._lib.hh_tap_shape(self._h, i, shape))
+            a = np.empty(tuple(shape), np.float32)
+            _lib.check(self._lib.hh_tap_read(self._h, i, a.ctypes.data))
+            out[self._lib.hh_tap_name(self._h, i).decode()] = a
+        return out
+
+
+class HigherHRNet(EngineModule):
+    def __init__(self, num_kpts: int, C: int = 32):
+        super().__init__()
+        self.num_kpts = num_kpts
+        self.C = C
+        self.num_deconv_layers = 1
+        self._init_engine(higher_hrnet_rows(num_kpts, C), lambda lib: lib.hh_create(num_kpts, C, 1))
+
+    def forward_raw(self, images: Tensor, out: tuple[Tensor, Tensor] | None = None) -> tuple[Tensor, Tensor]:
+        """-> (init_heatmaps [B,2K,H/4,W/4], deconv_heatmaps [B,K,H/2,W/2]) fp32.
+        `out` = preallocated result tensors (keeps the pointers, hence the cached hipGraph, stable)."""
+        x = self._check_input(images)
+        B, _, H, W = x.shape
         K = self.num_kpts
         if out is not None:
             init, dec = out
@@ -115,17 +140,3 @@ class HigherHRNet(nn.Module):
         init, dec = self.forward_raw(images)
         K = self.num_kpts
         return [init[:, :K], dec[:, :K]], init[:, K:]
-
-    # ---- debug taps for the parity tests
-    def set_taps(self, enable: bool) -> None:
-        self._lib.hh_set_taps(self._h, int(enable))
-
-    def read_taps(self) -> dict[str, np.ndarray]:
-        out = {}
-        for i in range(self._lib.hh_num_taps(self._h)):
-            shape = (C.c_int64 * 4)()
-            _lib.check(self._lib.hh_tap_shape(self._h, i, shape))
-            a = np.empty(tuple(shape), np.float32)
-            _lib.check(self._lib.hh_tap_read(self._h, i, a.ctypes.data))
-            out[self._lib.hh_tap_name(self._h, i).decode()] = a
-        return out

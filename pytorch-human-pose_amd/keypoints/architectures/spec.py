@@ -3,7 +3,7 @@
 The drop-in contract is the reference's *state-dict key names*
 (`/root/reference/src/keypoints/architectures/hrnet.py:29-385`,
 `higher_hrnet.py:7-64`): 1810 keys for W32.  The compute graph itself lives in the HIP
-engine (`csrc/plan.cpp`); Python only needs containers that own parameters under the same
+engine (`csrc/engine.cpp`); Python only needs containers that own parameters under the same
 names, so this module enumerates `(dotted_path, kind, ctor_args)` rows and
 `attach_modules` hangs real `nn.Conv2d` / `nn.BatchNorm2d` / `nn.ConvTranspose2d`
 leaves at those paths (so `.modules()`-based initialisers such as
@@ -106,6 +106,30 @@ def higher_hrnet_rows(num_kpts: int, C: int) -> Iterator[Row]:
         yield _conv(f"{rp}.conv2", C, C, 3, 1)
         yield _bn(f"{rp}.bn2", C)
     yield _conv(f"{dp}.final_layer", C, K, 1, 1, True)
+
+
+def classification_hrnet_rows(C: int, num_classes: int = 1000) -> Iterator[Row]:
+    """Rows for ClassificationHRNet (classification/architectures/hrnet.py:7-74): 4-scale backbone + head."""
+    yield from backbone_rows(C, "backbone", False)
+    widths, outs = [C, 2 * C, 4 * C, 8 * C], [128, 256, 512, 1024]
+    hp = "classification_head"
+    for i in range(4):
+        up, cin, cout, mid = f"{hp}.chann_incr_blocks.{i}", widths[i], outs[i], outs[i] // 4
+        yield _conv(f"{up}.conv1", cin, mid, 1, 1)
+        yield _bn(f"{up}.bn1", mid)
+        yield _conv(f"{up}.conv2", mid, mid, 3, 1)
+        yield _bn(f"{up}.bn2", mid)
+        yield _conv(f"{up}.conv3", mid, cout, 1, 1)
+        yield _bn(f"{up}.bn3", cout)
+        if cin != cout:
+            yield _conv(f"{up}.downsample.0", cin, cout, 1, 1)
+            yield _bn(f"{up}.downsample.1", cout)
+    for i in range(3):
+        yield _conv(f"{hp}.downsample_blocks.{i}.0", outs[i], outs[i + 1], 3, 2, True)
+        yield _bn(f"{hp}.downsample_blocks.{i}.1", outs[i + 1])
+    yield _conv(f"{hp}.final_conv.0", 1024, 2048, 1, 1, True)
+    yield _bn(f"{hp}.final_conv.1", 2048)
+    yield (f"{hp}.classifier", "linear", (2048, num_classes))
 
 
 class _Node(nn.Module):

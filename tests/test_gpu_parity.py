@@ -175,3 +175,16 @@ def test_end_to_end_model_call(pkg, synth):
     assert res.kpts_scores.shape == rj.shape[:2] and np.array_equal(res.kpts_scores, rj[..., 2]) and np.array_equal(res.obj_scores, rs)
     exp = orc.transform_coords(rj[..., :2], center, scale, (384, 256)).reshape(rj.shape[0], 17, 2)
     assert np.allclose(res.kpts_coords, exp, atol=1e-3)
+
+
+def test_classification_hrnet_cfg1_vs_reference_golden(pkg):
+    """BASELINE.json configs[0] through the HIP engine: ClassificationHRNet-W32, one 224x224 image."""
+    net = pkg.ClassificationHRNet(32, 1000)
+    sd = {k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 11)) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    net.to(DEV).eval()
+    x = torch.from_numpy(pkg.synth.synth_images(1, 224, 224, 11)).to(DEV)
+    logits = net(x).cpu().numpy()
+    ref = np.load(os.path.join(GOLDEN, "cls_forward.npz"))["logits"]
+    _close(logits, ref, "logits")
+    assert int(logits.argmax()) == int(ref.argmax())

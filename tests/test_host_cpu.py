@@ -30,6 +30,13 @@ def test_state_dict_keys_match_engine_and_reference_count(pkg, C):
     assert n_params == {32: 28645331, 48: 63827139}[C]
 
 
+def test_classifier_state_dict_and_flops(pkg):
+    net = pkg.ClassificationHRNet(32, 1000)
+    assert net.engine_param_names() == list(net.state_dict().keys())
+    assert sum(p.numel() for p in net.parameters()) == 41232680
+    assert abs(net.forward_flops(1, 224, 224) / 2e9 - 8.921) < 2e-3
+
+
 def test_algorithmic_flops_match_survey(pkg):
     assert abs(pkg.HigherHRNet(17, 32).forward_flops(1, 512, 512) / 2e9 - 46.203) < 1e-3
     assert abs(pkg.HigherHRNet(17, 48).forward_flops(1, 640, 640) / 2e9 - 149.469) < 1e-3

@@ -136,3 +136,20 @@ def test_flip_tta_oracle(pkg, synth):
         hms, tags = ofw.flip_tta(x, sd, 17)
     for name, t in (("hm_q", hms[0]), ("hm_h", hms[1]), ("tags0", tags[0]), ("tags1", tags[1])):
         assert np.allclose(t.numpy(), g[name], rtol=1e-4, atol=1e-4 * np.abs(g[name]).max()), name
+
+
+def test_classification_hrnet_oracle_cfg1(pkg, synth):
+    """BASELINE.json configs[0]: ClassificationHRNet-W32 on one 224x224 image, CPU only."""
+    import importlib
+    from torch import nn
+    spec = importlib.import_module(pkg.__name__ + ".keypoints.architectures.spec")
+    root = nn.Module()
+    spec.attach_modules(root, spec.classification_hrnet_rows(32, 1000))
+    sd = {k: torch.from_numpy(synth.synth_param(k, v.shape, 11)) for k, v in root.state_dict().items()}
+    assert sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k) == 41232680  # BASELINE.md
+    x = torch.from_numpy(synth.synth_images(1, 224, 224, 11))
+    with torch.no_grad():
+        logits = ofw.classification_hrnet(x, sd)
+    ref = np.load(os.path.join(GOLDEN, "cls_forward.npz"))["logits"]
+    assert logits.shape == ref.shape == (1, 1000)
+    assert np.allclose(logits.numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
