@@ -188,3 +188,69 @@ def test_classification_hrnet_cfg1_vs_reference_golden(pkg):
     ref = np.load(os.path.join(GOLDEN, "cls_forward.npz"))["logits"]
     _close(logits, ref, "logits")
     assert int(logits.argmax()) == int(ref.argmax())
+
+
+def _decode_both(pkg, hm_q, hm_h, tags, K, maxp=30, det=0.05, tthr=0.5):
+    parser = pkg.MPPEHeatmapParser(K, maxp, det, tthr)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None].to(DEV)  # noqa: E731
+    j, s = parser.to_lists(*parser.decode_batch_device(t(hm_q), t(hm_h), [t(x) for x in tags]))[0]
+    rj, rs = orc.decode(hm_q, hm_h, tags, max_people=maxp, det_thr=det, tag_thr=tthr)
+    assert j.shape == rj.shape and np.array_equal(j, rj) and np.array_equal(s, rs)
+    return j, s
+
+
+def test_decode_degenerate_and_edge_inputs(pkg, synth):
+    """Edge cases of the decode domain, each bit-exact against the oracle: empty maps, constant maps (every pixel a
+    tied peak), negative-only maps, peaks on the image border, people caps 1 and 32, K != 17, non-square and large maps."""
+    rs = np.random.RandomState(0)
+    K, hq, wq = 17, 40, 40
+    z = lambda *s: np.zeros(s, np.float32)  # noqa: E731
+    # all zeros -> no candidate above det_thr -> fallback person (grouping.py:262-269)
+    j, s = _decode_both(pkg, z(K, hq, wq), z(K, 2 * hq, 2 * wq), [z(K, hq, wq)], K)
+    assert j.shape[0] == 1 and np.all(j[0, :, 2] == np.float32(0.01))
+    # constant positive maps: every pixel is a tied local maximum above det_thr
+    c = np.full((K, hq, wq), 0.5, np.float32)
+    _decode_both(pkg, c, np.full((K, 2 * hq, 2 * wq), 0.5, np.float32), [z(K, hq, wq)], K)
+    # strictly negative maps (no zeros among the peaks of a plateau-free random field)
+    _decode_both(pkg, -rs.uniform(0.1, 1, (K, hq, wq)).astype(np.float32), -rs.uniform(0.1, 1, (K, 2 * hq, 2 * wq)).astype(np.float32),
+                 [rs.randn(K, hq, wq).astype(np.float32)], K)
+    # single peaks in the four corners / on the borders: adjust and refine clamp at the edges
+    hm_q, hm_h = z(K, hq, wq), z(K, 2 * hq, 2 * wq)
+    tg = z(K, hq, wq) + 1.0
+    for k, (y, x) in enumerate([(0, 0), (0, wq - 1), (hq - 1, 0), (hq - 1, wq - 1), (0, 17), (hq - 1, 5), (9, 0), (30, wq - 1)]):
+        hm_q[k, y, x] = 0.9
+        hm_h[k, 2 * y, 2 * x] = 0.8
+    _decode_both(pkg, hm_q, hm_h, [tg], K)
+    # people caps and a non-COCO joint count (joints_order falls back to 0..K-1)
+    for maxp in (1, 32):
+        a, b, t, _ = synth.synth_decode_maps(K, 48, 48, 12, seed=50 + maxp)
+        _decode_both(pkg, a, b, t, K, maxp=maxp)
+    a, b, t, _ = synth.synth_decode_maps(5, 40, 56, 4, seed=60, emb=2)
+    _decode_both(pkg, a, b, t, 5)
+    # a large, non-square map: 768 x 1024 model input (tiles straddle the border in y: 768 = 12 tiles, 1024 = 16)
+    a, b, t, _ = synth.synth_decode_maps(K, 192, 256, 6, seed=70)
+    _decode_both(pkg, a, b, t, K)
+
+
+def test_error_paths_raise(pkg):
+    net, _ = _net(pkg, 32, 0)
+    with pytest.raises(pkg._lib.HHError):
+        net(torch.zeros(1, 3, 100, 128, device=DEV))  # H not a multiple of 32
+    parser = pkg.MPPEHeatmapParser(17, 30, 0.05, 0.5)
+    with pytest.raises(pkg._lib.HHError):
+        t = torch.zeros(1, 17, 40, 40, device=DEV)
+        parser.decode_batch_device(t, torch.zeros(1, 17, 80, 80, device=DEV), [t] * 5)  # E > 4
+    with pytest.raises(pkg._lib.HHError):
+        pkg.MPPEHeatmapParser(17, 33, 0.05, 0.5)  # max_num_people > 32
+
+
+def test_forward_odd_batch_and_repeatability(pkg):
+    net, sd = _net(pkg, 32, 0)
+    x = torch.from_numpy(pkg.synth.synth_images(3, 128, 192, 5)).to(DEV)
+    h1, t1 = net(x)
+    h2, t2 = net(x)
+    assert torch.equal(h1[0], h2[0]) and torch.equal(h1[1], h2[1]) and torch.equal(t1, t2)  # deterministic
+    with torch.no_grad():
+        rh, rt = ofw.higher_hrnet(x.cpu(), sd, 17)
+    _close(h1[1].cpu().numpy(), rh[1].numpy(), "hm_h")
+    _close(t1.cpu().numpy(), rt.numpy(), "tags")
