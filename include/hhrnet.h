@@ -100,6 +100,13 @@ const char *hh_tap_name(const hh_net *net, int index);
 int hh_tap_shape(const hh_net *net, int index, int64_t shape[4]); /* N,C,H,W of the last forward */
 int hh_tap_read(hh_net *net, int index, float *host_nchw);        /* synchronous */
 
+/* InferenceKeypointsModel.prepare_input on the device (keypoints/model.py:70-76; resize-align warp of
+ * base/transforms/utils.py:89-97): `image_hwc` uint8 RGB [h,w,3] (device), `dst_to_src` the INVERSE of the 2x3 affine
+ * that get_affine_transform returns (cv2.warpAffine maps every destination pixel back), output fp32 NCHW [3,H,W] = Normalize(ToTensor(warpAffine(image))).  Bilinear,
+ * constant-0 border, intermediate rounded to uint8 as cv2 does (float weights, not cv2's fixed-point tables). */
+int hh_preprocess_u8(const unsigned char *image_hwc, int h, int w, const double dst_to_src[6], float *out_nchw, int H, int W,
+                     const float mean[3], const float stdv[3], void *stream);
+
 /* Flip test-time augmentation, keypoints/model.py:85-94 (COCO_FLIP_INDEX: keypoints/transforms.py:11).
  * hh_flip_images: out = flip(images, W axis), fp32 NCHW.
  * hh_flip_merge : hm[b,k] = (hm[b,k] + flip_w(hm_flipped[b, perm[k]])) / 2  in place for `hm`

@@ -120,6 +120,14 @@ int hh_conv_config(int cfg, int out[7])
     return 0;
 }
 
+int hh_preprocess_u8(const unsigned char *image_hwc, int h, int w, const double dst_to_src[6], float *out_nchw, int H, int W,
+                     const float mean[3], const float stdv[3], void *stream)
+{
+    if (!image_hwc || !out_nchw || h <= 0 || w <= 0 || H <= 0 || W <= 0) { hh_set_error("hh_preprocess_u8: bad argument"); return 1; }
+    HH_CHECK_HIP(launch_preprocess(image_hwc, h, w, dst_to_src, out_nchw, H, W, mean, stdv, (hipStream_t)stream));
+    return 0;
+}
+
 int hh_flip_images(const float *images, float *out, int B, int C, int H, int W, void *stream)
 {
     HH_CHECK_HIP(launch_flip_images(images, out, B, C, H, W, (hipStream_t)stream));

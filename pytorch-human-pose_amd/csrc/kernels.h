@@ -85,6 +85,8 @@ hipError_t launch_upadd(const UpAddParams &p, hipStream_t s);
 hipError_t launch_avgpool(const bf16_raw *in, int in_cs, float *out, int B, int HW, int C, hipStream_t s);
 hipError_t launch_linear(const float *x, const float *w, const float *bias, float *y, int B, int K, int N, hipStream_t s);
 
+hipError_t launch_preprocess(const unsigned char *img, int h, int w, const double inv[6], float *out, int H, int W,
+                             const float mean[3], const float stdv[3], hipStream_t s);
 hipError_t launch_flip_images(const float *in, float *out, int B, int C, int H, int W, hipStream_t s);
 hipError_t launch_flip_merge(float *hm, int64_t hm_bs, const float *hmf, int64_t hmf_bs, const float *tf, int64_t tf_bs,
                              float *to, int64_t to_bs, const int32_t *perm_dev, int B, int K, int h, int w, hipStream_t s);

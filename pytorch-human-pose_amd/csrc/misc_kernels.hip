@@ -168,3 +168,37 @@ hipError_t launch_linear(const float *x, const float *w, const float *bias, floa
     hipLaunchKernelGGL(linear_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, x, w, bias, y, K, N);
     return hipGetLastError();
 }
+
+// InferenceKeypointsModel.prepare_input on the GPU (keypoints/model.py:70-76 + base/transforms/utils.py:89-97):
+// inverse-mapped bilinear affine warp of a uint8 HWC image with a constant-0 border, rounded to uint8 like
+// cv2.warpAffine's output, then ToTensor (/255) and Normalize -> fp32 NCHW.  float64 coordinates/weights so the
+// result is identical to keypoints/transforms_utils.py::warp_affine (the host restatement).
+__global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char *__restrict__ img, int h, int w, double i00, double i01,
+                                                         double i02, double i10, double i11, double i12, float *__restrict__ out,
+                                                         int H, int W, float m0, float m1, float m2, float s0, float s1, float s2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i % W;
+    const double sx = i00 * x + i01 * y + i02, sy = i10 * x + i11 * y + i12;
+    const double fx0 = floor(sx), fy0 = floor(sy);
+    const long x0 = (long)fx0, y0 = (long)fy0;
+    const double fx = sx - fx0, fy = sy - fy0;
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        auto tap = [&](long yy, long xx) -> double {
+            return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (double)(float)img[((size_t)yy * w + xx) * 3 + c] : 0.0;
+        };
+        const double v = (tap(y0, x0) * (1 - fx) + tap(y0, x0 + 1) * fx) * (1 - fy) + (tap(y0 + 1, x0) * (1 - fx) + tap(y0 + 1, x0 + 1) * fx) * fy;
+        const float u8 = (float)fmin(fmax(rint(v), 0.0), 255.0);
+        out[(size_t)c * H * W + i] = (u8 / 255.0f - mean[c]) / stdv[c];
+    }
+}
+hipError_t launch_preprocess(const unsigned char *img, int h, int w, const double inv[6], float *out, int H, int W,
+                             const float mean[3], const float stdv[3], hipStream_t s)
+{
+    hipLaunchKernelGGL(preprocess_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, img, h, w, inv[0], inv[1], inv[2], inv[3], inv[4],
+                       inv[5], out, H, W, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
+    return hipGetLastError();
+}

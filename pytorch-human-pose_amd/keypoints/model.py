@@ -13,7 +13,9 @@ from torch import Tensor, nn
 from .. import _lib
 from .grouping import MPPEHeatmapParser
 from .results import InferenceKeypointsResult
-from .transforms_utils import COCO_FLIP_INDEX, IMAGENET_MEAN, IMAGENET_STD, resize_align_multi_scale
+import ctypes as C
+
+from .transforms_utils import COCO_FLIP_INDEX, IMAGENET_MEAN, IMAGENET_STD, affine_matrix, get_multi_scale_size
 
 COCO_LIMBS = [(15, 13), (13, 11), (16, 14), (14, 12), (11, 12), (5, 11), (6, 12), (5, 6), (5, 7), (6, 8), (7, 9), (8, 10),
               (1, 2), (0, 1), (0, 2), (1, 3), (2, 4), (3, 5), (4, 6)]
@@ -52,10 +54,20 @@ class InferenceKeypointsModel:
         self.net.load_state_dict(parse_checkpoint(ckpt["module"]["model"]))
 
     def prepare_input(self, image: np.ndarray):
-        """model.py:70-76: resize-align -> ToTensor -> Normalize -> [1,3,h,w] on device"""
-        resized, center, scale = resize_align_multi_scale(image, self.input_size, 1, 1)
-        x = (resized.astype(np.float32) / 255.0 - IMAGENET_MEAN) / IMAGENET_STD
-        x = torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))[None].to(self.device)
+        """model.py:70-76: resize-align -> ToTensor -> Normalize -> [1,3,h,w] on device.  Only the raw uint8 image
+        crosses PCIe; warp + normalisation run in hh_preprocess_u8."""
+        size, center, scale = get_multi_scale_size(image, self.input_size, 1, 1)
+        fwd = np.vstack([affine_matrix(center, scale, size), [0, 0, 1]])
+        m = np.ascontiguousarray(np.linalg.inv(fwd)[:2], dtype=np.float64)  # destination -> source, as warp_affine()
+        raw = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8)).to(self.device)
+        x = torch.empty((1, 3, size[1], size[0]), device=self.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.hh_preprocess_u8(raw.data_ptr(), image.shape[0], image.shape[1],
+                                                  m.ctypes.data_as(C.POINTER(C.c_double)), x.data_ptr(), size[1], size[0],
+                                                  IMAGENET_MEAN.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  IMAGENET_STD.ctypes.data_as(C.POINTER(C.c_float)), stream))
+        self._keep_raw = raw
         return x, center, scale
 
     @torch.no_grad()

@@ -254,3 +254,19 @@ def test_forward_odd_batch_and_repeatability(pkg):
         rh, rt = ofw.higher_hrnet(x.cpu(), sd, 17)
     _close(h1[1].cpu().numpy(), rh[1].numpy(), "hm_h")
     _close(t1.cpu().numpy(), rt.numpy(), "tags")
+
+
+def test_gpu_preprocessing_matches_host_restatement(pkg):
+    """hh_preprocess_u8 == Normalize(ToTensor(warp_affine(image))) of keypoints/transforms_utils.py, exactly."""
+    import importlib
+    tu = importlib.import_module(pkg.__name__ + ".keypoints.transforms_utils")
+    net, _ = _net(pkg, 32, 0)
+    model = pkg.InferenceKeypointsModel(net, input_size=256, device=DEV)
+    for shape in ((200, 300, 3), (301, 177, 3), (256, 256, 3)):
+        img = np.random.RandomState(shape[0]).randint(0, 256, shape).astype(np.uint8)
+        x, center, scale = model.prepare_input(img)
+        resized, c2, s2 = tu.resize_align_multi_scale(img, 256, 1, 1)
+        ref = (resized.astype(np.float32) / np.float32(255.0) - tu.IMAGENET_MEAN) / tu.IMAGENET_STD
+        assert tuple(center) == tuple(c2) and tuple(scale) == tuple(s2)
+        assert x.shape[1:] == (3,) + resized.shape[:2]
+        assert np.array_equal(x[0].cpu().numpy(), np.ascontiguousarray(ref.transpose(2, 0, 1)))
