@@ -142,6 +142,12 @@ int hh_decode(hh_decoder *dec, const float *hm_q, int64_t hm_q_bstride, const fl
 int hh_parse(hh_decoder *dec, const float *hm_full, const float *tags_full, int E, int B, int H, int W, int adjust,
              int refine, float *joints, float *scores, int32_t *num_people, void *stream);
 
+/* Multi-scale test-time augmentation (BASELINE.json configs[3]; an extension: the reference only calls its resize helper
+ * with scale 1, keypoints/model.py:73): dst[B,K,H,W] (+)= weight * bilinear(src[B,K,h,w] -> HxW) with the arithmetic of
+ * F.interpolate(mode="bilinear", align_corners=False); init != 0 overwrites dst.  Batch strides in elements.            */
+int hh_resize_accumulate(const float *src, int64_t src_bstride, int B, int K, int h, int w, float *dst, int64_t dst_bstride, int H,
+                         int W, float weight, int init, void *stream);
+
 /* Candidates of the last hh_decode/hh_parse call (MPPEHeatmapParser.top_k, grouping.py:147-170),
  * copied to host: tags_k [B,K,max_people,E], coords_k [B,K,max_people,2] (x,y), scores_k [B,K,max_people].
  * Synchronous; for parity tests.                                                        */

@@ -44,3 +44,6 @@ hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, float *
 // refine: mean tag per person, then full-map argmax for every missing joint
 hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev,
                          unsigned long long *ws_best, int32_t *ws_jobs, const float *cellmax, float *tagb, hipStream_t s);
+// dst (+)= weight * bilinear(src -> HxW), torch CPU arithmetic, any ratio (multi-scale heatmap aggregation)
+hipError_t launch_resize_accumulate(const float *src, int64_t src_bs, int B, int K, int h, int w, float *dst, int64_t dst_bs, int H,
+                                    int W, float weight, int init, hipStream_t s);

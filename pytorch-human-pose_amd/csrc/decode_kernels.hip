@@ -856,3 +856,31 @@ hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32
     hipLaunchKernelGGL(refine_apply_kernel, dim3(M, src.B), dim3(64), 0, s, src, M, joints, num_people, ws_best);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------ multi-scale aggregation (extension)
+// dst (+)= weight * bilinear(src -> HxW): F.interpolate(mode="bilinear", align_corners=False) arithmetic for any
+// scale ratio.  The reference only ever calls its resize helper with scale 1 (keypoints/model.py:73); averaging the
+// heatmaps of several input scales is the HigherHRNet-paper test-time augmentation named by BASELINE.json configs[3].
+__global__ __launch_bounds__(256) void resize_accumulate_kernel(const float *__restrict__ src, int64_t src_bs, int K, int h, int w,
+                                                                float *__restrict__ dst, int64_t dst_bs, int H, int W, float sy,
+                                                                float sx, float weight, int init)
+{
+    const int k = blockIdx.y, b = blockIdx.z;
+    const float *img = src + (size_t)b * src_bs + (size_t)k * h * w;
+    float *o = dst + (size_t)b * dst_bs + (size_t)k * H * W;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const Lin lx = src_index(w, sx, x);
+        for (int y = blockIdx.x; y < H; y += gridDim.x) {
+            const float v = weight * bilerp(img, w, src_index(h, sy, y), lx);
+            o[(size_t)y * W + x] = init ? v : o[(size_t)y * W + x] + v;
+        }
+    }
+}
+hipError_t launch_resize_accumulate(const float *src, int64_t src_bs, int B, int K, int h, int w, float *dst, int64_t dst_bs, int H,
+                                    int W, float weight, int init, hipStream_t s)
+{
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    hipLaunchKernelGGL(resize_accumulate_kernel, dim3(H < 64 ? H : 64, K, B), dim3(256), 0, s, src, src_bs, K, h, w, dst, dst_bs, H, W,
+                       sy, sx, weight, init);
+    return hipGetLastError();
+}

@@ -122,6 +122,14 @@ int hh_parse(hh_decoder *dec, const float *hm_full, const float *tags_full, int 
     return dec->run(src, adjust, refine, joints, scores, num_people, (hipStream_t)stream);
 }
 
+int hh_resize_accumulate(const float *src, int64_t src_bstride, int B, int K, int h, int w, float *dst, int64_t dst_bstride, int H,
+                         int W, float weight, int init, void *stream)
+{
+    if (!src || !dst || B <= 0 || K <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) { hh_set_error("hh_resize_accumulate: bad argument"); return 1; }
+    HH_CHECK_HIP(launch_resize_accumulate(src, src_bstride, B, K, h, w, dst, dst_bstride, H, W, weight, init, (hipStream_t)stream));
+    return 0;
+}
+
 int hh_decoder_read_topk(hh_decoder *dec, float *tags_k, int32_t *coords_k, float *scores_k)
 {
     if (!dec->lastB) { hh_set_error("hh_decoder_read_topk: nothing decoded yet"); return 1; }

@@ -53,6 +53,13 @@ struct Builder {
         n.ops.push_back(o);
     }
 
+    void dep(int from, int to)
+    {
+        Op o;
+        o.kind = OP_DEP; o.dep_from = from; o.lane = to;
+        n.ops.push_back(o);
+    }
+
     // ---- parameter registration in the reference's state_dict order
     void p_conv(const std::string &name, int cin, int cout, int k, bool bias = false)
     {
@@ -315,6 +322,9 @@ struct Builder {
                 join(nsc + 1);
                 lane = nsc;  // the new branch starts on its own lane
                 cb(q, "0", "1", w[nsc - 1], w[nsc], 3, 2, x[nsc - 1], x[nsc], 1);
+                // write-after-read: branch nsc-1 of the next stage updates x[nsc-1] in place (conv2 of its first
+                // BasicBlock) and must not start before the transition conv above has consumed it
+                dep(nsc, nsc - 1);
                 lane = 0;
                 for (int i = 0; i <= nsc; ++i) tap("stages." + std::to_string(s) + "#" + std::to_string(i), x[i], w[i]);
             } else {
@@ -582,6 +592,14 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 for (int m = 0; m < nrec; ++m)
                     if (m != l) HH_CHECK_HIP(hipStreamWaitEvent(L[l], e[m], 0));
             if (op.nlanes > lanes_open) lanes_open = op.nlanes;
+            break;
+        }
+        case OP_DEP: {
+            if (!multi) break;
+            hipEvent_t e;
+            if (next_event(&e)) return 1;
+            HH_CHECK_HIP(hipEventRecord(e, L[op.dep_from]));
+            HH_CHECK_HIP(hipStreamWaitEvent(L[op.lane], e, 0));
             break;
         }
         case OP_INCONVERT:

@@ -45,7 +45,7 @@ struct TensorDesc {
     bool zero_init = false;
 };
 
-enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR };
+enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP };
 
 struct Op {
     OpKind kind = OP_CONV;
@@ -62,6 +62,7 @@ struct Op {
     int tap = -1;
     int lane = 0;     // execution lane (HIP stream): resolution branches / fusion outputs run concurrently
     int nlanes = 0;   // OP_JOIN: all-to-all barrier over lanes [0, nlanes)
+    int dep_from = 0; // OP_DEP: `lane` waits for everything enqueued so far on lane dep_from
 };
 
 struct TapInfo {

@@ -53,6 +53,54 @@ class InferenceKeypointsModel:
         ckpt = torch.load(ckpt_path, map_location="cpu")
         self.net.load_state_dict(parse_checkpoint(ckpt["module"]["model"]))
 
+    def prepare_input_scaled(self, image: np.ndarray, current_scale: float, min_scale: float):
+        """prepare_input for one entry of a multi-scale test (get_multi_scale_size, base/transforms/utils.py:60-86)."""
+        size, center, scale = get_multi_scale_size(image, self.input_size, current_scale, min_scale)
+        fwd = np.vstack([affine_matrix(center, scale, size), [0, 0, 1]])
+        m = np.ascontiguousarray(np.linalg.inv(fwd)[:2], dtype=np.float64)
+        raw = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8)).to(self.device)
+        x = torch.empty((1, 3, size[1], size[0]), device=self.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.hh_preprocess_u8(raw.data_ptr(), image.shape[0], image.shape[1],
+                                                  m.ctypes.data_as(C.POINTER(C.c_double)), x.data_ptr(), size[1], size[0],
+                                                  IMAGENET_MEAN.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  IMAGENET_STD.ctypes.data_as(C.POINTER(C.c_float)), stream))
+        self._keep_raw = raw
+        return x, center, scale
+
+    @torch.no_grad()
+    def multi_scale_maps(self, raw_image: np.ndarray, scales=(0.5, 1.0, 2.0)):
+        """Multi-scale (+ flip if use_flip) test of BASELINE.json configs[3] -- an EXTENSION, the reference has no
+        aggregation code.  Every scale runs the same forward/flip-merge as a single-scale call; its two stage heatmaps
+        are bilinearly resized to the scale-1 pass's 1/4 and 1/2 resolutions and averaged over the scales
+        (hh_resize_accumulate); tags are taken from the scale-1 pass only (as the HigherHRNet paper's test code does
+        for the grouping keys).  Returns ([hm_1/4, hm_1/2], tags_list, x_base, center, scale) ready for from_preds."""
+        assert 1.0 in scales, "the scale-1 pass provides the tags and the output geometry"
+        mn = min(scales)
+        xb, center, scale = self.prepare_input_scaled(raw_image, 1.0, mn)
+        hms_b, tags_b = self.forward_tta(xb)
+        K = self.net.num_kpts
+        acc = [torch.empty_like(hms_b[0].contiguous()), torch.empty_like(hms_b[1].contiguous())]
+        stream = torch.cuda.current_stream(xb.device).cuda_stream
+        wgt = 1.0 / len(scales)
+        first = True
+        for s in scales:
+            hms = hms_b if s == 1.0 else self.forward_tta(self.prepare_input_scaled(raw_image, s, mn)[0])[0]
+            for st in range(2):
+                src = hms[st]
+                _lib.check(self._lib.hh_resize_accumulate(src.data_ptr(), src.stride(0), 1, K, src.shape[2], src.shape[3],
+                                                          acc[st].data_ptr(), acc[st].stride(0), acc[st].shape[2], acc[st].shape[3],
+                                                          wgt, int(first), stream))
+            first = False
+        return acc, [t.contiguous() for t in tags_b], xb, center, scale
+
+    def call_multi_scale(self, raw_image: np.ndarray, annot: list | None = None, scales=(0.5, 1.0, 2.0)) -> InferenceKeypointsResult:
+        hms, tags, xb, center, scale = self.multi_scale_maps(raw_image, scales)
+        self.model_input_shape = tuple(xb.shape[-2:])
+        return InferenceKeypointsResult.from_preds(raw_image, annot, xb[0], hms, tags, self.limbs, scale, center, self.det_thr,
+                                                   self.tag_thr, self.max_num_people, parser=self._parser)
+
     def prepare_input(self, image: np.ndarray):
         """model.py:70-76: resize-align -> ToTensor -> Normalize -> [1,3,h,w] on device.  Only the raw uint8 image
         crosses PCIe; warp + normalisation run in hh_preprocess_u8."""

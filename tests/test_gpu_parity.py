@@ -270,3 +270,56 @@ def test_gpu_preprocessing_matches_host_restatement(pkg):
         assert tuple(center) == tuple(c2) and tuple(scale) == tuple(s2)
         assert x.shape[1:] == (3,) + resized.shape[:2]
         assert np.array_equal(x[0].cpu().numpy(), np.ascontiguousarray(ref.transpose(2, 0, 1)))
+
+
+def test_resize_accumulate_and_multi_scale_extension(pkg):
+    """hh_resize_accumulate is torch's bilinear for arbitrary ratios (checked bit-exactly against the oracle's pinned
+    restatement), and the multi-scale test (BASELINE configs[3], W48) equals the same aggregation done with the oracle."""
+    lib = pkg._lib.load()
+    rs = np.random.RandomState(1)
+    for (h, w, H, W) in [(40, 56, 80, 112), (80, 112, 40, 56), (17, 23, 100, 77), (64, 64, 64, 64)]:
+        src = torch.from_numpy(rs.randn(2, 5, h, w).astype(np.float32)).to(DEV)
+        dst = torch.full((2, 5, H, W), 7.0, device=DEV)
+        st = torch.cuda.current_stream().cuda_stream
+        pkg._lib.check(lib.hh_resize_accumulate(src.data_ptr(), src.stride(0), 2, 5, h, w, dst.data_ptr(), dst.stride(0), H, W, 0.5, 1, st))
+        pkg._lib.check(lib.hh_resize_accumulate(src.data_ptr(), src.stride(0), 2, 5, h, w, dst.data_ptr(), dst.stride(0), H, W, 0.5, 0, st))
+        ref = np.stack([orc.bilinear(src[b].cpu().numpy(), H, W) for b in range(2)])
+        half = (np.float32(0.5) * ref).astype(np.float32)
+        assert np.array_equal(dst.cpu().numpy(), (half + half).astype(np.float32))
+    net, sd = _net(pkg, 48, 3)
+    model = pkg.InferenceKeypointsModel(net, det_thr=0.05, tag_thr=0.5, use_flip=True, input_size=128, device=DEV)
+    img = np.random.RandomState(9).randint(0, 255, (150, 220, 3)).astype(np.uint8)
+    scales = (0.5, 1.0, 2.0)
+    hms, tags, xb, center, scale = model.multi_scale_maps(img, scales)
+    assert tuple(xb.shape[-2:]) == (128, 256)
+    exp = [np.zeros(hms[0].shape[1:], np.float32), np.zeros(hms[1].shape[1:], np.float32)]
+    for s in scales:
+        x, _, _ = model.prepare_input_scaled(img, s, min(scales))
+        assert tuple(x.shape[-2:]) == (int(128 * s), int(256 * s))
+        h_s, _ = model.forward_tta(x)
+        for st in range(2):
+            r = orc.bilinear(h_s[st][0].cpu().numpy(), exp[st].shape[1], exp[st].shape[2])
+            exp[st] = (exp[st] + np.float32(1.0 / 3.0) * r).astype(np.float32) if s != scales[0] else (np.float32(1.0 / 3.0) * r).astype(np.float32)
+    for st in range(2):
+        assert np.array_equal(hms[st][0].cpu().numpy(), exp[st])
+    res = model.call_multi_scale(img, None, scales)
+    rj, rsc = orc.decode(exp[0], exp[1], [t[0].cpu().numpy() for t in tags], max_people=30, det_thr=0.05, tag_thr=0.5)
+    assert np.array_equal(res.kpts_scores, rj[..., 2]) and np.array_equal(res.obj_scores, rsc)
+
+
+def test_multi_lane_equals_single_lane_on_changing_inputs(pkg):
+    """The multi-stream schedule must give the single-stream result bit for bit on inputs and shapes that change
+    from call to call (a missing cross-lane dependency shows up as a run-to-run difference, and repeated identical
+    inputs would mask it)."""
+    lib = pkg._lib.load()
+    for C in (32, 48):
+        net, _ = _net(pkg, C, 3)
+        shapes = [(64, 128), (128, 256), (256, 512), (64, 64), (32, 32)]
+        xs = {(s, r): torch.from_numpy(pkg.synth.synth_images(1, s[0], s[1], 5 + r)).to(DEV) for s in shapes for r in range(3)}
+        lib.hh_set_multi_lane(net._h, 0)
+        ref = {k: [t.clone() for t in net.forward_raw(x)] for k, x in xs.items()}
+        lib.hh_set_multi_lane(net._h, 1)
+        for rep in range(6):
+            for k, x in xs.items():
+                i, d = net.forward_raw(x)
+                assert torch.equal(i, ref[k][0]) and torch.equal(d, ref[k][1]), (C, rep, k)
