@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO = os.path.join(CSRC, "libhhrnet.so")
+SO = os.environ.get("HH_LIB") or os.path.join(CSRC, "libhhrnet.so")  # HH_LIB: A/B-test another build of the same ABI
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hhrnet.h")
 _lib = None
 
@@ -55,7 +55,8 @@ def _sig(lib):
         "hh_tap_read": (i32, [vp, i32, vp]),
         "hh_profile_enable": (i32, [vp, i32]),
         "hh_profile_count": (i32, [vp]),
-        "hh_profile_get": (i32, [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_char_p)]),
+        "hh_profile_get": (i32, [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                           C.POINTER(C.c_char_p)]),
         "hh_conv_config": (i32, [i32, C.POINTER(C.c_int)]),
         "hh_debug_conv_bench": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp, i32, C.POINTER(C.c_float)]),
         "hh_debug_bb_bench": (i32, [i32, i32, i32, i32, C.POINTER(C.c_float), vp]),

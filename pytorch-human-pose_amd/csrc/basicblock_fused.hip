@@ -92,6 +92,9 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
     char *lds_w2 = lds_w1 + W_BYTES;
 
     const int tid = threadIdx.x;
+#ifndef HH_NO_CLK
+    if (p.clk && tid == 0) atomicMin(p.clk, wall_clock64());
+#endif
     const int wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
 
@@ -296,6 +299,9 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
         STAMP(6);
         STAMP(7);
     }
+#ifndef HH_NO_CLK
+    if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
+#endif
 }
 
 hipError_t bb_fused_init()

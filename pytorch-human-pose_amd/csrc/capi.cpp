@@ -102,7 +102,7 @@ int hh_tap_read(hh_net *net, int index, float *host_nchw) { return hh_tap_read_i
 
 int hh_profile_enable(hh_net *net, int enable) { net->prof_enabled = enable != 0; net->prof_used = 0; return 0; }
 int hh_profile_count(const hh_net *net) { return (int)net->prof_used; }
-int hh_profile_get(hh_net *net, int i, int *cfg, double *flops, float *ms, const char **layer)
+int hh_profile_get(hh_net *net, int i, int *cfg, double *flops, float *ms, float *kernel_ms, const char **layer)
 {
     if (i < 0 || i >= (int)net->prof_used) { hh_set_error("hh_profile_get: index out of range"); return 1; }
     const ProfRecord &r = net->prof[i];
@@ -110,6 +110,12 @@ int hh_profile_get(hh_net *net, int i, int *cfg, double *flops, float *ms, const
     HH_CHECK_HIP(hipEventElapsedTime(ms, r.e0, r.e1));
     *cfg = r.cfg; *flops = r.flops;
     *layer = net->layers[net->ops[r.op].layer].conv.c_str();
+    *kernel_ms = -1.f;
+    if (r.slot >= 0 && net->d_clk && net->clk_khz > 0) {
+        unsigned long long t[2];
+        HH_CHECK_HIP(hipMemcpy(t, net->d_clk + 2 * r.slot, 16, hipMemcpyDeviceToHost));
+        if (t[1] > t[0]) *kernel_ms = (float)((double)(t[1] - t[0]) / net->clk_khz);
+    }
     return 0;
 }
 int hh_conv_config(int cfg, int out[7])

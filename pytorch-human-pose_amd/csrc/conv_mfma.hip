@@ -79,6 +79,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     const int iy0 = oy0 * S - p.pad_y, ix0 = ox0 * S - p.pad_x;
 
     const int tid = threadIdx.x;
+#ifndef HH_NO_CLK
+    if (p.clk && tid == 0) atomicMin(p.clk, wall_clock64());
+#endif
     const int wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int wp = wave / WC, wc = wave % WC;
@@ -269,6 +272,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
             }
         }
     }
+#ifndef HH_NO_CLK
+    if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -574,6 +574,18 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         *e = lane_events[lane_events_used++];
         return 0;
     };
+    if (prof_enabled) {  // device-clock slots: starts = ~0, ends = 0
+        if (!d_clk) {
+            HH_CHECK_HIP(hipMalloc((void **)&d_clk, HH_PROF_SLOTS * 16));
+            int dev = 0, khz = 0;
+            HH_CHECK_HIP(hipGetDevice(&dev));
+            HH_CHECK_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+            clk_khz = khz;
+        }
+        std::vector<unsigned long long> init(HH_PROF_SLOTS * 2);
+        for (int i = 0; i < HH_PROF_SLOTS; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0; }
+        HH_CHECK_HIP(hipMemcpy(d_clk, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+    }
     int lanes_open = 1;  // lanes [0, lanes_open) have work that the caller's stream must wait for at the end
     for (const Op &op : ops) {
         hipStream_t s = L[op.lane];
@@ -657,6 +669,8 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr = &prof[prof_used++];
                 pr->op = (int)(&op - ops.data());
                 pr->cfg = HH_CFG_BB_FUSED;
+                pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
+                if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
                 pr->flops = 2.0 * 2.0 * B * p.H * p.W * 32.0 * 32.0 * 9.0;
                 HH_CHECK_HIP(hipEventRecord(pr->e0, s));
             }
@@ -710,6 +724,8 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr = &prof[prof_used++];
                 pr->op = (int)(&op - ops.data());
                 pr->cfg = cfg;
+                pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
+                if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
                 pr->flops = 2.0 * B * p.Ho * p.Wo * (double)l.cin * l.cout * l.ks * l.ks;
                 HH_CHECK_HIP(hipEventRecord(pr->e0, s));
             }
@@ -789,6 +805,7 @@ hh_net::~hh_net()
     release_workspace();
     for (auto &r : prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     if (d_pool) hipFree(d_pool);
+    if (d_clk) hipFree(d_clk);
     if (d_fc_w) hipFree(d_fc_w);
     if (d_fc_b) hipFree(d_fc_b);
     for (auto &e : lane_events) hipEventDestroy(e);

@@ -75,6 +75,7 @@ struct ProfRecord {
     int op, cfg;
     double flops;
     hipEvent_t e0, e1;
+    int slot;  // index into d_clk ({min start, max end} device-clock ticks written by the kernel itself), -1 = none
 };
 
 struct GraphEntry {
@@ -108,6 +109,8 @@ struct hh_net {
     bool prof_enabled = false;
     std::vector<ProfRecord> prof;
     size_t prof_used = 0;
+    unsigned long long *d_clk = nullptr;  // [HH_PROF_SLOTS][2]
+    double clk_khz = 0;                   // hipDeviceAttributeWallClockRate
     // lanes 1..3: internal streams forked from / joined to the caller's stream (also inside hipGraph capture)
     hipStream_t lane_streams[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> lane_events;

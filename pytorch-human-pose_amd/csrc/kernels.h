@@ -26,6 +26,7 @@ struct ConvParams {
     int pad_y, pad_x;     // top/left zero padding
     int B, tiles_x, tiles_y, ncg;
     unsigned long long *stamps;  // diagnostic build (-DHH_STAMP) only
+    unsigned long long *clk;     // optional {min start, max end} of the launch in wall_clock64() ticks (profiling probe)
     const bf16_raw *zero;        // >= 16 zero bytes (16-B aligned): DMA source of out-of-image pixels (conv3x3_dma.hip)
 };
 
@@ -64,7 +65,9 @@ struct BBParams {
     int B, H, W;
     int tiles_x, tiles_y, ntiles;    // filled by bb_fused_launch
     unsigned long long *stamps;      // diagnostic build (-DHH_STAMP) only
+    unsigned long long *clk;         // optional {min start, max end} of the launch in wall_clock64() ticks
 };
+#define HH_PROF_SLOTS 1024   // launches per forward the device-clock probe can record
 #define HH_CFG_BB_FUSED 100  // pseudo instantiation index used by the profiler
 hipError_t bb_fused_init();
 hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s);

@@ -202,3 +202,4 @@ hipError_t launch_preprocess(const unsigned char *img, int h, int w, const doubl
                        inv[5], out, H, W, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
     return hipGetLastError();
 }
+

@@ -21,7 +21,8 @@ n = lib.hh_profile_count(net._h)
 cfg, fl, ms, name = C.c_int(), C.c_double(), C.c_float(), C.c_char_p()
 agg = collections.OrderedDict()
 for i in range(n):
-    lib.hh_profile_get(net._h, i, C.byref(cfg), C.byref(fl), C.byref(ms), C.byref(name))
+    kms = C.c_float()
+    lib.hh_profile_get(net._h, i, C.byref(cfg), C.byref(fl), C.byref(ms), C.byref(kms), C.byref(name))
     nm = name.value.decode()
     key = re.sub(r"blocks\.\d+\.scales_blocks\.(\d+)\.\d+", r"blocks.*.scales_blocks.\1.*", nm)
     key = re.sub(r"blocks\.\d+\.scales_fusion", "blocks.*.scales_fusion", key)

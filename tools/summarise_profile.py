@@ -1,0 +1,94 @@
+"""Condense the rocprofv3 outputs of tools/profile_round.sh into the tracked files under profiles/.
+
+    python3 tools/summarise_profile.py r01
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are KiB per dispatch, collected
+in separate passes; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes, so reads are doubled.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+out = os.path.join(root, "gpurun_out")
+prof = os.path.join(root, "profiles")
+
+
+def one(pattern):
+    hits = sorted(glob.glob(os.path.join(out, pattern), recursive=True), key=os.path.getsize)
+    if not hits:
+        sys.exit(f"missing {pattern}")
+    return hits[-1]
+
+
+def pmc(name, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    with open(one(f"{tag}_{name}/**/*counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter:
+                a = acc[r["Kernel_Name"]]
+                a[0] += float(r["Counter_Value"]); a[1] += 1
+    return {k: v[0] / v[1] * 1024.0 for k, v in acc.items()}  # bytes per launch
+
+
+stats = list(csv.DictReader(open(one(f"{tag}_stats/**/*kernel_stats.csv"))))
+serial = {r["Name"]: r for r in csv.DictReader(open(one(f"{tag}_serial/**/*kernel_stats.csv")))}
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+with open(os.path.join(prof, f"{tag}_bench_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev",
+                "SerialAverageNs", "SerialPercentage", "hbm_read_bytes_per_launch(2xFETCH_SIZE)", "hbm_write_bytes_per_launch"])
+    for r in stats:
+        n = r["Name"]
+        sr = serial.get(n, {})
+        w.writerow([n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"],
+                    sr.get("AverageNs", ""), sr.get("Percentage", ""), round(2 * fetch.get(n, 0.0)), round(write.get(n, 0.0))])
+
+
+def short(n):
+    return n if len(n) <= 84 else n[:81] + "..."
+
+
+lines = [f"# {tag} rocprofv3 summaries (bench.py default workload: HigherHRNet-W32, batch 32 @ 512x512, 1x MI355X)", "",
+         "Recipe: `bash tools/profile_round.sh " + tag + "` = `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py "
+         "--no-cpu-baseline`, then separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes (`--steps 3 --warmup 1`).",
+         "`avg us (overlapped)` is the default bench (4 internal streams + the decode stream: kernels share the chip, so each one's "
+         "wall duration is longer than its isolated duration); `avg us (serial)` is `bench.py --single-lane --sequential` (one kernel "
+         "at a time) and is the per-launch duration that bench.py's `roofline` probe reports from HIP events.",
+         "HBM read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB, averaged per launch.",
+         f"Full table: {tag}_bench_kernel_stats.csv.  `__amd_rocclr_copyBuffer`/`fillBuffer` rows are the one-off weight uploads "
+         "and workspace clears of model setup, not part of a step.", "",
+         "| kernel | calls | avg us (overlapped) | avg us (serial) | % time (serial) | HBM read MB/launch | HBM write MB/launch |",
+         "|---|---|---|---|---|---|---|"]
+for r in stats:
+    if float(r["Percentage"]) < 0.2:
+        continue
+    n = r["Name"]
+    sr = serial.get(n)
+    lines.append(f"| `{short(n)}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(sr['AverageNs']) / 1e3 if sr else float('nan'):.1f} | "
+                 f"{float(sr['Percentage']) if sr else float('nan'):.2f} | "
+                 f"{2 * fetch.get(n, 0.0) / 1e6:.1f} | {write.get(n, 0.0) / 1e6:.1f} |")
+for which in ("stats", "serial"):
+    for ln in open(os.path.join(out, f"{tag}_{which}.log"), errors="replace"):
+        if ln.startswith('{"metric"'):
+            lines += ["", f"bench.py line of the traced `{which}` run (profiler attached, so slower than an untraced run):", "", "```", ln.strip(), "```"]
+open(os.path.join(prof, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+
+# per-launch HBM bytes keyed the way bench.py names kernels
+traffic = {}
+for n in set(fetch) | set(write):
+    total = 2 * fetch.get(n, 0.0) + write.get(n, 0.0)
+    m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", n)
+    if m:
+        traffic["conv_mfma_kernel<KS=%s,S=%s,KC=%s,NT=%s,WC=%s,PT=%s,TW=%s>" % m.groups()] = round(total, -5)
+    elif n.startswith("bb_fused_kernel"):
+        traffic["bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)"] = round(total, -5)
+json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --no-cpu-baseline --steps 3 --warmup 1` "
+                     f"(profiles/{tag}_summary.md); read = 2*FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB, averaged per launch",
+           "bytes_per_launch": traffic}, open(os.path.join(prof, f"traffic_{tag}.json"), "w"), indent=1)
+print("\n".join(lines[:20]))
