@@ -28,6 +28,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 PKG = "pytorch-human-pose_amd"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
@@ -252,6 +253,14 @@ def main():
                 "share_of_conv_time": round(d["kms"] / total_ms, 3),
                 "all_conv_tflops": round(sum(v["flops"] for v in per_cfg.values()) / (total_ms * 1e-3) / 1e12, 2),
             }
+        # decode half against the HBM roofline: compulsory bytes (read every network output once) over the
+        # time of one hh_decode call alone; the kernels are latency/VALU bound by design, so this is small
+        dec_bytes = 6684672.0 * B
+        line["decode_roofline"] = {
+            "bound": "hbm", "achieved": round(dec_bytes / parts[1] / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(dec_bytes / parts[1] / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic_for("hh_decode (all kernels of one call)"),
+            "algorithmic_bytes_per_call": dec_bytes, "ms_per_call": round(parts[1] * 1e3, 3),
+        }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, sd, uniq)
         print(json.dumps(line), flush=True)

@@ -145,6 +145,22 @@ int hh_decode(hh_decoder *dec, const float *hm_q, int64_t hm_q_bstride, const fl
 int hh_parse(hh_decoder *dec, const float *hm_full, const float *tags_full, int E, int B, int H, int W, int adjust,
              int refine, float *joints, float *scores, int32_t *num_people, void *stream);
 
+/* Training loss of keypoints/loss.py, each fused with its gradient (all pointers device memory, fp32).
+ * `scratch`: >= max(1024, 2*B) doubles.  Sums are taken in double in a fixed order (results do not depend on the launch).
+ *
+ * hh_loss_heatmaps = HeatmapsLoss.forward (loss.py:12-16): *loss = mean((pred - target)^2 * mask[:,None]);
+ *   pred [B,K,h,w] with batch stride pred_bstride (a channel slice of a wider tensor is fine), target [B,K,h,w] and
+ *   mask [B,h,w] contiguous; if grad != NULL, grad[b,k] (batch stride grad_bstride) = d loss / d pred.
+ * hh_loss_ae_grouping = AEGroupingLoss.forward (loss.py:20-61): push_pull[0] = push, [1] = pull, both / batch size
+ *   (calculate_loss, loss.py:90-92, scales them by 1e-3 afterwards); tags [B,K,h,w]; joints [B,P,K,3] int32 (x, y, vis)
+ *   padded to P people, num_people[b] of them valid, x in [0,w), y in [0,h) wherever vis > 0 (the caller checks);
+ *   if grad != NULL, push_scale * d push + pull_scale * d pull is ADDED to grad (zero it first).                    */
+int hh_loss_heatmaps(const float *pred, int64_t pred_bstride, const float *target, const float *mask, int B, int K, int h, int w,
+                     float *loss, float *grad, int64_t grad_bstride, double *scratch, void *stream);
+int hh_loss_ae_grouping(const float *tags, int64_t tags_bstride, const int32_t *joints, const int32_t *num_people, int B, int P, int K,
+                        int h, int w, float *push_pull, float *grad, int64_t grad_bstride, float push_scale, float pull_scale,
+                        double *scratch, void *stream);
+
 /* Multi-scale test-time augmentation (BASELINE.json configs[3]; an extension: the reference only calls its resize helper
  * with scale 1, keypoints/model.py:73): dst[B,K,H,W] (+)= weight * bilinear(src[B,K,h,w] -> HxW) with the arithmetic of
  * F.interpolate(mode="bilinear", align_corners=False); init != 0 overwrites dst.  Batch strides in elements.            */

@@ -134,6 +134,26 @@ int hh_preprocess_u8(const unsigned char *image_hwc, int h, int w, const double 
     return 0;
 }
 
+int hh_loss_heatmaps(const float *pred, int64_t pred_bstride, const float *target, const float *mask, int B, int K, int h, int w,
+                     float *loss, float *grad, int64_t grad_bstride, double *scratch, void *stream)
+{
+    if (!pred || !target || !mask || !loss || !scratch || B <= 0 || K <= 0 || h <= 0 || w <= 0) { hh_set_error("hh_loss_heatmaps: bad argument"); return 1; }
+    if ((h * w) % 4 || pred_bstride % 4 || (grad && grad_bstride % 4)) { hh_set_error("hh_loss_heatmaps: h*w and the batch strides must be multiples of 4"); return 1; }
+    HH_CHECK_HIP(launch_masked_mse(pred, pred_bstride, target, mask, B, K, h, w, loss, grad, grad_bstride, scratch, (hipStream_t)stream));
+    return 0;
+}
+
+int hh_loss_ae_grouping(const float *tags, int64_t tags_bstride, const int32_t *joints, const int32_t *num_people, int B, int P, int K,
+                        int h, int w, float *push_pull, float *grad, int64_t grad_bstride, float push_scale, float pull_scale,
+                        double *scratch, void *stream)
+{
+    if (!tags || !joints || !num_people || !push_pull || !scratch || B <= 0 || P <= 0 || K <= 0 || h <= 0 || w <= 0) { hh_set_error("hh_loss_ae_grouping: bad argument"); return 1; }
+    if (P > 2048) { hh_set_error("hh_loss_ae_grouping: at most 2048 people per image"); return 1; }
+    HH_CHECK_HIP(launch_ae_grouping(tags, tags_bstride, joints, num_people, B, P, K, h, w, push_pull, grad, grad_bstride, push_scale,
+                                    pull_scale, scratch, (hipStream_t)stream));
+    return 0;
+}
+
 int hh_flip_images(const float *images, float *out, int B, int C, int H, int W, void *stream)
 {
     HH_CHECK_HIP(launch_flip_images(images, out, B, C, H, W, (hipStream_t)stream));

@@ -93,3 +93,11 @@ hipError_t launch_preprocess(const unsigned char *img, int h, int w, const doubl
 hipError_t launch_flip_images(const float *in, float *out, int B, int C, int H, int W, hipStream_t s);
 hipError_t launch_flip_merge(float *hm, int64_t hm_bs, const float *hmf, int64_t hmf_bs, const float *tf, int64_t tf_bs,
                              float *to, int64_t to_bs, const int32_t *perm_dev, int B, int K, int h, int w, hipStream_t s);
+
+// Training loss (loss_kernels.hip).  scratch: >= max(HH_LOSS_SCRATCH, 2*B) doubles of device memory.
+#define HH_LOSS_SCRATCH 1024
+hipError_t launch_masked_mse(const float *pred, int64_t pred_bs, const float *target, const float *mask, int B, int K, int h, int w,
+                             float *loss, float *grad, int64_t grad_bs, double *scratch, hipStream_t s);
+hipError_t launch_ae_grouping(const float *tags, int64_t tags_bs, const int32_t *joints, const int32_t *num_people, int B, int P, int K,
+                              int h, int w, float *push_pull, float *grad, int64_t grad_bs, float push_scale, float pull_scale,
+                              double *scratch, hipStream_t s);

@@ -118,3 +118,57 @@ def synth_decode_maps(
             for e in range(emb):
                 tags[e][k][m] = (tagval[e] + tag_noise * rs.standard_normal(int(m.sum()))).astype(np.float32)
     return hm_q, hm_h, tags, people
+
+
+# ----------------------------------------------------------------------------------------
+# Training batch of BASELINE.json configs[2]: random people -> joints per stage, target heatmaps
+# rendered by the restated HeatmapGenerator (sigma 2), masks.  Shapes follow keypoints/datasets/coco.py:140-164.
+# ----------------------------------------------------------------------------------------
+def synth_train_targets(batch: int, num_kpts: int, input_size: int, people, seed: int = 0, vis_prob: float = 0.8,
+                        mask_holes: bool = False):
+    """-> (heatmaps [2 x f32 [B,K,s,s]], masks [2 x f32 [B,s,s]], joints [2 x list of int32 [P_b,K,3]]) for the 1/4 and
+    1/2 stages.  `people` = int or per-image list (0 allowed)."""
+    from .keypoints.targets import HeatmapGenerator, JointsGenerator
+
+    rs = np.random.RandomState(777001 + seed)
+    counts = [people] * batch if np.isscalar(people) else list(people)
+    sizes = [input_size // 4, input_size // 2]
+    hms = [np.zeros((batch, num_kpts, s, s), np.float32) for s in sizes]
+    masks = [np.ones((batch, s, s), np.float32) for s in sizes]
+    joints = [[], []]
+    for b in range(batch):
+        P = counts[b]
+        cx, cy = rs.uniform(0.1, 0.9, P) * input_size, rs.uniform(0.1, 0.9, P) * input_size
+        raw = np.zeros((P, num_kpts, 3))
+        for p in range(P):
+            raw[p, :, 0] = cx[p] + rs.normal(0, input_size / 12, num_kpts)  # some fall outside the image on purpose
+            raw[p, :, 1] = cy[p] + rs.normal(0, input_size / 12, num_kpts)
+            raw[p, :, 2] = (rs.uniform(size=num_kpts) < vis_prob) * rs.randint(1, 3, num_kpts)
+        for i, s in enumerate(sizes):
+            sc = raw.copy()
+            sc[..., :2] *= s / input_size
+            j = JointsGenerator(s)(sc)
+            joints[i].append(j)
+            hms[i][b] = HeatmapGenerator(num_kpts, s, 2)(j)
+            if mask_holes:  # crowd regions are masked out of the heatmap loss (coco.py:167-180)
+                y0, x0 = rs.randint(0, s // 2, 2)
+                masks[i][b, y0:y0 + s // 4, x0:x0 + s // 3] = 0
+    return hms, masks, joints
+
+
+def synth_train_preds(hms, seed: int = 0):
+    """Predictions for a loss test: target heatmaps + N(0, 0.1) per stage, tags ~ N(0, 1) at the 1/4 stage."""
+    rs = np.random.RandomState(9000 + seed)
+    pred = [(h + rs.normal(0, 0.1, h.shape)).astype(np.float32) for h in hms]
+    tags = rs.normal(0, 1.0, hms[0].shape).astype(np.float32)
+    return pred, tags
+
+
+def edit_loss_case(tag: str, joints):
+    """Hand-made edge cases of the loss fixtures (shared by tools/make_golden.py and the tests)."""
+    if tag == "b2_dups":  # two people sharing a pixel for one joint; people with no / a single visible joint
+        joints[0][0][1, 5] = joints[0][0][0, 5] = (7, 9, 1)
+        joints[0][0][2, :, :] = 0
+        joints[0][1][1, :, 2] = 0
+        joints[0][1][1, 3] = (4, 4, 1)
+    return joints

@@ -1,11 +1,12 @@
 """-m gpu: the HIP path (through the C-ABI) against the oracle and the golden vectors."""
+import importlib
 import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, PKG
 from oracle import decode as orc
 from oracle import forward as ofw
 
@@ -323,3 +324,70 @@ def test_multi_lane_equals_single_lane_on_changing_inputs(pkg):
             for k, x in xs.items():
                 i, d = net.forward_raw(x)
                 assert torch.equal(i, ref[k][0]) and torch.equal(d, ref[k][1]), (C, rep, k)
+
+
+def test_evaluate_images_packs_what_single_calls_return(pkg):
+    """bin/eval.py:18-49 through the drop-in wrapper: per-image results in COCO layout, in dataset order."""
+    ev = importlib.import_module(PKG + ".keypoints.evaluation")
+    net, _ = _net(pkg, 32, 4)
+    model = pkg.InferenceKeypointsModel(net, det_thr=0.05, tag_thr=0.5, use_flip=False, input_size=128, device=DEV)
+    rs = np.random.RandomState(3)
+    images = [rs.randint(0, 255, (100 + 20 * i, 160, 3)).astype(np.uint8) for i in range(3)]
+    out = ev.evaluate_images(model, images, [11, 12, 13])
+    exp = []
+    for i, im in enumerate(images):
+        r = model(im, None)
+        exp += ev.pack_coco_results(11 + i, r.kpts_coords, r.obj_scores)
+    assert out == exp and len(out) >= 3 and len(out[0]["keypoints"]) == 51
+
+
+def _loss_case(pkg, case):
+    tag, B, size, people, seed, holes = case
+    hms, masks, joints = pkg.synth.synth_train_targets(B, 17, size, people, seed=seed, mask_holes=holes)
+    joints = pkg.synth.edit_loss_case(tag, joints)
+    pred, tags = pkg.synth.synth_train_preds(hms, seed)
+    return hms, masks, joints, pred, tags
+
+
+def test_ae_loss_and_gradients_match_reference(pkg):
+    """AEKeypointsLoss.calculate_loss (loss.py:64-93) and the gradients of hm0+hm1+push+pull (module.py:50-59) through
+    torch autograd on the HIP loss, against (i) the reference's values + autograd gradients (tests/golden/loss.npz) and
+    (ii) the oracle on every element.  fp32; sums are taken in a different order, hence rtol 2e-5."""
+    import json
+    from oracle import loss as ol
+    lossmod = importlib.import_module(PKG + ".keypoints.loss")
+    g = np.load(os.path.join(GOLDEN, "loss.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "loss_meta.json")))
+    fn = lossmod.AEKeypointsLoss()
+    for case in meta["cases"]:
+        tag = case[0]
+        hms, masks, joints, pred, tags = _loss_case(pkg, case)
+        K = 17
+        # predictions laid out the way the net emits them: stage-0 heatmaps and tags are channel slices of one tensor
+        init = torch.from_numpy(np.concatenate([pred[0], tags], 1)).to(DEV).requires_grad_()
+        dec = torch.from_numpy(pred[1]).to(DEV).requires_grad_()
+        hl, push, pull = fn.calculate_loss([init[:, :K], dec], init[:, K:], [torch.from_numpy(h).to(DEV) for h in hms],
+                                           [torch.from_numpy(m).to(DEV) for m in masks], joints)
+        total = hl[0] + hl[1] + push[0] + pull[0]
+        total.backward()
+        got = np.array([hl[0].item(), hl[1].item(), push[0].item(), pull[0].item(), total.item()], np.float32)
+        np.testing.assert_allclose(got, g[f"{tag}.losses"], rtol=2e-5, atol=1e-9)
+        ohl, opush, opull, ogp, ogt = ol.calculate_loss(pred, tags, hms, masks, joints)
+        gi = init.grad.cpu().numpy()
+        np.testing.assert_allclose(gi[:, :K], ogp[0], rtol=2e-5, atol=1e-10)
+        np.testing.assert_allclose(dec.grad.cpu().numpy(), ogp[1], rtol=2e-5, atol=1e-10)
+        np.testing.assert_allclose(gi[:, K:], ogt, rtol=2e-5, atol=1e-10)
+        flat = gi[:, K:].ravel()
+        assert np.array_equal(np.flatnonzero(flat), g[f"{tag}.g_tags_idx"])
+        np.testing.assert_allclose(flat[g[f"{tag}.g_tags_idx"]], g[f"{tag}.g_tags_val"], rtol=2e-5, atol=1e-10)
+        for i, gg in enumerate((gi[:, :K], dec.grad.cpu().numpy())):
+            np.testing.assert_allclose(gg.ravel()[g[f"{tag}.g_pred{i}_idx"]], g[f"{tag}.g_pred{i}_val"], rtol=2e-5, atol=1e-10)
+    # loss scaling arrives through grad_output (GradScaler), and error paths stay python exceptions
+    t = torch.zeros(1, 17, 8, 8, device=DEV, requires_grad=True)
+    pu, pl = lossmod.AEGroupingLoss()(t, [np.array([[[1, 1, 1]] * 17, [[2, 2, 1]] * 17], np.int32)])
+    (pu * 1024.0).backward()
+    assert abs(pu.item() - 0.5) < 1e-7 and pl.item() == 0 and float(t.grad.abs().max()) == 0.0  # equal tags: exp(0), zero slope
+    with pytest.raises(IndexError):
+        lossmod.AEGroupingLoss()(t, [np.array([[[8, 1, 1]] * 17], np.int32)])
+    with pytest.raises(pkg._lib.HHError):
+        lossmod.HeatmapsLoss()(torch.zeros(1, 17, 8, 8), torch.zeros(1, 17, 8, 8), torch.ones(1, 8, 8))

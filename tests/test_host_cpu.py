@@ -92,3 +92,40 @@ def test_parse_checkpoint_prefixes(pkg):
     mod = importlib.import_module(PKG + ".keypoints.model")
     out = mod.parse_checkpoint({"module.net.backbone.conv1.weight": 1, "_orig_mod.net.init_heatmaps_head.bias": 2})
     assert out == {"backbone.conv1.weight": 1, "init_heatmaps_head.bias": 2}
+
+
+def test_coco_result_packing_matches_reference_layout():
+    """bin/eval.py:27-48: [x, y, 1] * K float64 keypoints, category 1, score = the person score as a float."""
+    ev = importlib.import_module(PKG + ".keypoints.evaluation")
+    coords = np.arange(2 * 17 * 2, dtype=np.float32).reshape(2, 17, 2) / 3
+    scores = np.array([0.75, 0.125], np.float32)
+    out = ev.pack_coco_results(139, coords, scores)
+    assert [r["image_id"] for r in out] == [139, 139] and all(r["category_id"] == 1 for r in out)
+    for p, r in enumerate(out):
+        k = np.asarray(r["keypoints"]).reshape(17, 3)
+        assert np.array_equal(k[:, 0], coords[p, :, 0].astype(np.float64)) and np.array_equal(k[:, 1], coords[p, :, 1].astype(np.float64))
+        assert np.all(k[:, 2] == 1) and isinstance(r["score"], float) and r["score"] == float(scores[p])
+    assert ev.pack_coco_results(1, np.zeros((0, 17, 2), np.float32), np.zeros((0,), np.float32)) == []
+    assert ev.image_id_from_path("/data/COCO/images/val2017/000000000139.jpg") == 139
+
+
+def test_target_generators_properties():
+    """HeatmapGenerator / JointsGenerator (datasets/coco.py:76-137) restated from the text: peak 1.0 at the joint,
+    max-composition of overlapping blobs, clipping at the border, invisible and out-of-bounds joints dropped."""
+    tg = importlib.import_module(PKG + ".keypoints.targets")
+    raw = np.zeros((3, 17, 3))
+    raw[0, 0] = (10.7, 20.2, 2); raw[0, 1] = (-3, 5, 2); raw[0, 2] = (5, 64, 1); raw[0, 3] = (63, 0, 1)
+    raw[1, 0] = (12, 20, 1)
+    j = tg.JointsGenerator(64)(raw)
+    assert j.dtype == np.int32 and j.shape == (2, 17, 3)  # the all-zero third person is dropped
+    assert j[0, 0].tolist() == [10, 20, 1] and j[0, 1].tolist() == [0, 0, 0] and j[0, 2].tolist() == [0, 0, 0] and j[0, 3].tolist() == [63, 0, 1]
+    hm = tg.HeatmapGenerator(17, 64, 2)(j)
+    assert hm.shape == (17, 64, 64) and hm.dtype == np.float32 and hm.max() == 1.0
+    assert hm[0, 20, 10] == 1.0 and hm[0, 20, 12] == 1.0  # two people, same joint type: max, not sum
+    assert abs(hm[0, 20, 11] - np.exp(-1 / 8)) < 1e-6 and hm[1].max() == 0 and hm[3, 0, 63] == 1.0
+    assert hm[0, 20, 10 - 8] == 0 and hm[0, 20, 10 - 7] > 0  # support is 6*sigma+3 = 15 pixels
+    lossmod = importlib.import_module(PKG + ".keypoints.loss")
+    packed, counts = lossmod.pack_joints([j, np.zeros((0, 17, 3), np.int32)], 17, 64, 64)
+    assert packed.shape == (2, 2, 17, 3) and counts.tolist() == [2, 0] and np.array_equal(packed[0], j)
+    with pytest.raises(IndexError):
+        lossmod.pack_joints([np.array([[[64, 0, 1]] * 17])], 17, 64, 64)

@@ -153,3 +153,34 @@ def test_classification_hrnet_oracle_cfg1(pkg, synth):
     ref = np.load(os.path.join(GOLDEN, "cls_forward.npz"))["logits"]
     assert logits.shape == ref.shape == (1, 1000)
     assert np.allclose(logits.numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def _loss_case(synth, case):
+    tag, B, size, people, seed, holes = case
+    hms, masks, joints = synth.synth_train_targets(B, 17, size, people, seed=seed, mask_holes=holes)
+    joints = synth.edit_loss_case(tag, joints)
+    pred, tags = synth.synth_train_preds(hms, seed)
+    return hms, masks, joints, pred, tags
+
+
+def test_loss_oracle_matches_reference_losses_and_autograd(synth):
+    """AEKeypointsLoss.calculate_loss (loss.py:64-93) + torch autograd, captured from the reference."""
+    from oracle import loss as ol
+
+    g = np.load(os.path.join(GOLDEN, "loss.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "loss_meta.json")))
+    for case in meta["cases"]:
+        tag = case[0]
+        hms, masks, joints, pred, tags = _loss_case(synth, case)
+        hl, push, pull, gp, gt = ol.calculate_loss(pred, tags, hms, masks, joints)
+        ref = g[f"{tag}.losses"]
+        np.testing.assert_allclose([hl[0], hl[1], push, pull], ref[:4], rtol=2e-6, atol=1e-9)
+        for i in range(2):
+            flat = gp[i].ravel()
+            np.testing.assert_allclose(flat[g[f"{tag}.g_pred{i}_idx"]], g[f"{tag}.g_pred{i}_val"], rtol=1e-6, atol=1e-12)
+            sums = g[f"{tag}.g_pred{i}_sums"]  # [signed sum (cancels heavily), sum of magnitudes]
+            np.testing.assert_allclose(np.abs(flat.astype(np.float64)).sum(), sums[1], rtol=1e-6)
+            np.testing.assert_allclose(flat.astype(np.float64).sum(), sums[0], atol=1e-6 * sums[1])
+        nz = np.flatnonzero(gt.ravel())
+        assert np.array_equal(nz, g[f"{tag}.g_tags_idx"])
+        np.testing.assert_allclose(gt.ravel()[nz], g[f"{tag}.g_tags_val"], rtol=2e-5, atol=1e-10)

@@ -13,6 +13,7 @@ What is imported from the reference (and therefore *pinned* by these fixtures):
   * src.keypoints.grouping.MPPEHeatmapParser                     (decode, a12-a17)
   * munkres.Munkres 1.1.4                                        (assignment, a14)
   * src.base.transforms.utils.get_multi_scale_size               (resize geometry, a10)
+  * src.keypoints.loss.AEKeypointsLoss                           (training loss + autograd gradients, a20)
 What is NOT importable here (cv2 / torchvision missing) and is restated inline with the
 same torch calls the reference makes: the three F.interpolate(bilinear,
 align_corners=False) + stack/mean lines of results.py:48-67,225-230 and the flip-TTA
@@ -264,8 +265,55 @@ def geometry_fixtures():
     print("geometry rows", len(rows))
 
 
+# (tag, B, input_size, people per image, seed, mask holes, hand-made edits)
+LOSS_CASES = [
+    ("b3_128", 3, 128, [3, 1, 0], 1, True),
+    ("b4_256", 4, 256, [10, 7, 2, 5], 2, True),
+    ("b2_dups", 2, 128, [4, 2], 3, False),
+    ("b2_empty", 2, 128, [0, 0], 4, False),
+]
+
+
+def loss_fixtures():
+    """AEKeypointsLoss.calculate_loss (loss.py:64-93) + the sum of module.py:50-59, fp32 on CPU, and torch autograd's
+    gradients of that sum w.r.t. the two predicted heatmap stacks and the predicted tag map."""
+    from src.keypoints.loss import AEKeypointsLoss
+
+    out = {}
+    for tag, B, size, people, seed, holes in LOSS_CASES:
+        K = 17
+        hms, masks, joints = synth.synth_train_targets(B, K, size, people, seed=seed, mask_holes=holes)
+        joints = synth.edit_loss_case(tag, joints)
+        p_np, t_np = synth.synth_train_preds(hms, seed)
+        pred = [torch.from_numpy(p).requires_grad_() for p in p_np]
+        tags = torch.from_numpy(t_np).requires_grad_()
+        loss_fn = AEKeypointsLoss()
+        hl, push, pull = loss_fn.calculate_loss(pred, tags, [torch.from_numpy(h) for h in hms], [torch.from_numpy(m) for m in masks], joints)
+        total = hl[0] + hl[1] + push[0] + pull[0]
+        total = total if torch.is_tensor(total) else torch.tensor(float(total))
+        if total.requires_grad:
+            total.backward()
+        z = lambda t: np.zeros(tuple(t.shape), np.float32) if t.grad is None else t.grad.numpy()
+        f = lambda v: np.float32(v.item() if torch.is_tensor(v) else v)
+        out[f"{tag}.losses"] = np.array([f(hl[0]), f(hl[1]), f(push[0]), f(pull[0]), f(total)], np.float32)
+        # dense heatmap gradients: float64 sums + 512 sampled entries per stage; the tag gradient is sparse: store it whole
+        for i in range(2):
+            g = z(pred[i]).ravel()
+            idx = np.random.RandomState(5 + i).randint(0, g.size, 512)
+            out[f"{tag}.g_pred{i}_idx"], out[f"{tag}.g_pred{i}_val"] = idx.astype(np.int64), g[idx]
+            out[f"{tag}.g_pred{i}_sums"] = np.array([g.astype(np.float64).sum(), np.abs(g.astype(np.float64)).sum()])
+        gt = z(tags).ravel()
+        nz = np.flatnonzero(gt)
+        out[f"{tag}.g_tags_idx"], out[f"{tag}.g_tags_val"] = nz.astype(np.int64), gt[nz]
+        print(tag, out[f"{tag}.losses"], "nonzero tag grads", nz.size)
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+    json.dump({"cases": [list(c) for c in LOSS_CASES]}, open(os.path.join(OUT, "loss_meta.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "decode", "flip", "munkres", "geometry"]
+    which = sys.argv[1:] or ["net", "decode", "flip", "munkres", "geometry", "loss"]
+    if "loss" in which:
+        loss_fixtures()
     if "munkres" in which:
         munkres_fixtures()
     if "geometry" in which:

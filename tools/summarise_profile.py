@@ -88,6 +88,9 @@ for n in set(fetch) | set(write):
         traffic["conv_mfma_kernel<KS=%s,S=%s,KC=%s,NT=%s,WC=%s,PT=%s,TW=%s>" % m.groups()] = round(total, -5)
     elif n.startswith("bb_fused_kernel"):
         traffic["bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)"] = round(total, -5)
+DECODE = ("stage_average", "nms_tile_topk", "topk_merge", "match_kernel", "adjust_scores", "refine_", "tag_bounds")
+traffic["hh_decode (all kernels of one call)"] = round(sum(2 * fetch.get(n, 0.0) + write.get(n, 0.0) for n in set(fetch) | set(write)
+                                                           if n.startswith(DECODE)), -5)
 json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --no-cpu-baseline --steps 3 --warmup 1` "
                      f"(profiles/{tag}_summary.md); read = 2*FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB, averaged per launch",
            "bytes_per_launch": traffic}, open(os.path.join(prof, f"traffic_{tag}.json"), "w"), indent=1)
