@@ -29,10 +29,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+// ReLU after the rounding, on the packed pair: as signed 16-bit integers every negative bf16 (sign bit set, -0 included)
+// is below zero and every non-negative one keeps its bits, so one v_pk_max_i16 replaces two canonicalise + two v_max_f32.
 __device__ __forceinline__ unsigned pack_relu_bf16x2(float a, float b)
 {
-    f32x2 f = {fmaxf(a, 0.f), fmaxf(b, 0.f)};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+    f32x2 f = {a, b};
+    const i16x2 v = __builtin_bit_cast(i16x2, __builtin_convertvector(f, bf16x2));
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, i16x2{0, 0}));
 }
 
 template <typename F, int... I>
@@ -48,7 +52,7 @@ __device__ __forceinline__ void static_for(F &&f)
 
 // 32 couts of one pixel: lanes (r,0) hold couts 8g..8g+3, lanes (r,1) couts 8g+4..8g+7 in acc[4g..4g+3].
 // Returns for m = 0,1 the 16 bytes (bf16, ReLU applied) of couts 16m+8h .. 16m+8h+7 of this lane's pixel.
-__device__ __forceinline__ void pack_rows16(const f32x16 &acc, bool zero, u32x4 out[2])
+__device__ __forceinline__ void pack_rows16(const f32x16 &acc, u32x4 out[2])
 {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -58,7 +62,7 @@ __device__ __forceinline__ void pack_rows16(const f32x16 &acc, bool zero, u32x4 
         // swap X[32..63] <-> Y[0..31]: lanes 0-31 end with (X,Y) = couts 16m..16m+7, lanes 32-63 with 16m+8..16m+15
         auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
         auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-        out[m] = zero ? u32x4{0u, 0u, 0u, 0u} : u32x4{s0[0], s1[0], s0[1], s1[1]};
+        out[m] = u32x4{s0[0], s1[0], s0[1], s1[1]};
     }
 }
 
@@ -168,6 +172,19 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
         });
     };
 
+    // Workgroup barrier that waits for LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would stall every
+    // wave until the next tile's prefetch loads (issued during conv1, consumed during conv2) and the previous tile's
+    // output stores have completed.
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // one 16-byte unit of the next patch: registers -> LDS (zero outside the image = conv1 padding)
+    auto write_patch_unit = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int u = tid + 256 * i;
+        if (u < P_UNITS)
+            *reinterpret_cast<u32x4 *>(lds_p + (u >> 2) * PS + (u & 3) * 16) = (pf_mask >> i) & 1u ? preg[i] : u32x4{0u, 0u, 0u, 0u};
+    };
+
     int t = blockIdx.x;
     if (t < p.ntiles) {
         pf_setup(t);
@@ -175,6 +192,21 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
     }
     write_patch();
     __syncthreads();
+
+    f32x16 acc2[4];             // conv2 accumulators; the finished tile is stored during the NEXT tile's conv1
+    bool prev = false;
+    bf16_raw *prev_out = p.out;  // + (oy0 * W + ox0) * out_cs of the finished tile
+    int prev_oy0 = 0, prev_ox0 = 0;
+    auto store_rows = [&](int q) {  // ReLU, bf16, 16 contiguous bytes per lane straight to HBM
+        const int oy = prev_oy0 + wave * 4 + q, ox = prev_ox0 + r;
+        u32x4 o[2];
+        pack_rows16(acc2[q], o);
+        if (oy < p.H && ox < p.W) {
+            bf16_raw *dst = prev_out + ((ptrdiff_t)(wave * 4 + q) * p.W + r) * p.out_cs + 8 * h;
+            *reinterpret_cast<u32x4 *>(dst) = o[0];
+            *reinterpret_cast<u32x4 *>(dst + 16) = o[1];
+        }
+    };
 
     for (; t < p.ntiles; t += gridDim.x) {
         const int b = t / tiles_per_img, tt = t % tiles_per_img;
@@ -213,92 +245,105 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
                 if constexpr (st < NPL) {  // one prefetch load per k-step
                     if (more) pf_load(ic);
                 }
+                if constexpr (st >= 12 && st < 16) {  // the previous tile's output rows leave while the MFMAs run
+                    if (prev) store_rows(st - 12);
+                }
 #pragma unroll
                 for (int q = 0; q < 5; ++q)
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st & 1]),
                                                                      __builtin_bit_cast(bf16x8, fb[st & 1][q]), acc[q], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x8, 5, 0);
+                if constexpr (st >= 12 && st < 16) {
+                    // the pack/store VALU work only overlaps the matrix pipe when it sits BETWEEN the MFMAs (in-order issue)
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x40, 2, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 5, 0);
+                }
             });
             STAMP(1);
+            // conv2's accumulators start as bn2 shift + residual: the centre of the input patch times an identity A
+            // fragment (exact: x * 1.0 in fp32), issued now because the patch buffer is recycled during conv2
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc2[q][4 * g + 0] = b2v[g].x; acc2[q][4 * g + 1] = b2v[g].y;
+                    acc2[q][4 * g + 2] = b2v[g].z; acc2[q][4 * g + 3] = b2v[g].w;
+                }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x4 x = *reinterpret_cast<const u32x4 *>(lds_p + ((wave * 4 + q + 2) * IW + r + 2) * PS + kk * 32 + h * 16);
+                    acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ident[kk]), __builtin_bit_cast(bf16x8, x),
+                                                                      acc2[q], 0, 0, 0);
+                }
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
                 const int gy = oy0 - 1 + (myx[q] >> 8), gx = ox0 - 1 + (myx[q] & 255);
                 // conv2 zero-pads the *feature map*: mid pixels outside the image are 0, not conv1(padding)
                 const bool outside = gy < 0 || gy >= p.H || gx < 0 || gx >= p.W;
                 u32x4 o[2];
-                pack_rows16(acc[q], outside, o);
+                pack_rows16(acc[q], o);
                 if (maddr[q] >= 0) {
                     *reinterpret_cast<u32x4 *>(lds_m + maddr[q]) = o[0];
                     *reinterpret_cast<u32x4 *>(lds_m + maddr[q] + 32) = o[1];
+                    if (outside) {  // only tiles on the image border have such lanes
+                        *reinterpret_cast<u32x4 *>(lds_m + maddr[q]) = u32x4{0u, 0u, 0u, 0u};
+                        *reinterpret_cast<u32x4 *>(lds_m + maddr[q] + 32) = u32x4{0u, 0u, 0u, 0u};
+                    }
                 }
             }
         }
-        __syncthreads();
         STAMP(2);
+        lds_barrier();  // mid tile visible; every wave is done reading the patch
+        STAMP(3);
 
-        // ================= conv2 + bn2 + residual + relu =================
-        f32x16 acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                acc[q][4 * g + 0] = b2v[g].x; acc[q][4 * g + 1] = b2v[g].y;
-                acc[q][4 * g + 2] = b2v[g].z; acc[q][4 * g + 3] = b2v[g].w;
-            }
+        // ================= conv2 + bn2 (+ residual already in acc2); the next patch goes to LDS meanwhile =================
         {
             u32x4 fa[2], fb[2][4];
             auto ld2 = [&](int st, int buf) {
-                if (st < 18) {
-                    const int tap = st >> 1, kk = st & 1, ky = tap / 3, kx = tap % 3;
-                    fa[buf] = *reinterpret_cast<const u32x4 *>(lds_w2 + ((tap * 4 + kk * 2 + h) * 32 + r) * 16);
+                const int tap = st >> 1, kk = st & 1, ky = tap / 3, kx = tap % 3;
+                fa[buf] = *reinterpret_cast<const u32x4 *>(lds_w2 + ((tap * 4 + kk * 2 + h) * 32 + r) * 16);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        fb[buf][q] = *reinterpret_cast<const u32x4 *>(lds_m + ((wave * 4 + q + ky) * MW + r + kx) * PS + kk * 32 + h * 16);
-                } else {  // steps 18,19: residual = identity x centre of the input patch
-                    const int kk = st - 18;
-                    fa[buf] = ident[kk];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        fb[buf][q] = *reinterpret_cast<const u32x4 *>(lds_p + ((wave * 4 + q + 2) * IW + r + 2) * PS + kk * 32 + h * 16);
-                }
+                for (int q = 0; q < 4; ++q)
+                    fb[buf][q] = *reinterpret_cast<const u32x4 *>(lds_m + ((wave * 4 + q + ky) * MW + r + kx) * PS + kk * 32 + h * 16);
             };
             ld2(0, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-            static_for<20>([&](auto ic) {
+            static_for<18>([&](auto ic) {
                 constexpr int st = decltype(ic)::value;
-                if (st + 1 < 20) {
+                if (st + 1 < 18) {
                     ld2(st + 1, (st + 1) & 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, st + 1 < 18 ? 5 : 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                }
+                if constexpr (st >= 2 && st - 2 < NPL) {
+                    if (more) write_patch_unit(std::integral_constant<int, st - 2>{});
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st & 1]),
-                                                                     __builtin_bit_cast(bf16x8, fb[st & 1][q]), acc[q], 0, 0, 0);
+                    acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st & 1]),
+                                                                      __builtin_bit_cast(bf16x8, fb[st & 1][q]), acc2[q], 0, 0, 0);
                 __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
             });
         }
-        STAMP(3);
-        __syncthreads();  // every wave is done with the mid tile and the patch
         STAMP(4);
-        if (more) write_patch();
-        // ---- epilogue: ReLU, bf16, 16 contiguous bytes per lane straight to HBM
-        bf16_raw *out_b = p.out + (size_t)b * p.H * p.W * p.out_cs;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int oy = oy0 + wave * 4 + q, ox = ox0 + r;
-            u32x4 o[2];
-            pack_rows16(acc[q], false, o);
-            if (oy < p.H && ox < p.W) {
-                bf16_raw *dst = out_b + ((size_t)oy * p.W + ox) * p.out_cs + 8 * h;
-                *reinterpret_cast<u32x4 *>(dst) = o[0];
-                *reinterpret_cast<u32x4 *>(dst + 16) = o[1];
-            }
-        }
+        lds_barrier();  // every wave is done with the mid tile; the next patch is visible
         STAMP(5);
-        __syncthreads();  // next patch visible
+        prev = true;
+        prev_oy0 = oy0; prev_ox0 = ox0;
+        prev_out = p.out + (((ptrdiff_t)b * p.H + oy0) * p.W + ox0) * p.out_cs;
         STAMP(6);
         STAMP(7);
     }
+    if (prev)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_rows(q);
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
 #endif

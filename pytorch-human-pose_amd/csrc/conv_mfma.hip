@@ -28,10 +28,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP's uint4 struct kept staging arrays in scratch
 
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b)
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+// Round a pair to bf16 and clamp it from below as signed 16-bit integers: floor = {0,0} is ReLU (every negative bf16,
+// -0 included, is a negative int16; non-negative ones keep their bits), floor = {-32768,-32768} is the identity.
+// One v_pk_max_i16 per pair instead of two canonicalise + two v_max_f32 on the fp32 values.
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b, i16x2 floor)
 {
     f32x2 f = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+    const i16x2 v = __builtin_bit_cast(i16x2, __builtin_convertvector(f, bf16x2));
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, floor));
 }
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
@@ -241,16 +246,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
         const size_t pix = ((size_t)b * p.Hob + Y) * p.Wob + X;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            if (p.relu)
+            if (p.relu && p.out_f32)  // (no layer of the net has both; the bf16 path clamps while packing)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[nt][pt][i] = fmaxf(acc[nt][pt][i], 0.f);
             if (p.out) {
+                const short fl = p.relu ? (short)0 : (short)-32768;
+                const i16x2 floor = {fl, fl};
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const unsigned x0 = pack_bf16x2(acc[nt][pt][8 * m + 0], acc[nt][pt][8 * m + 1]);
-                    const unsigned x1 = pack_bf16x2(acc[nt][pt][8 * m + 2], acc[nt][pt][8 * m + 3]);
-                    const unsigned y0 = pack_bf16x2(acc[nt][pt][8 * m + 4], acc[nt][pt][8 * m + 5]);
-                    const unsigned y1 = pack_bf16x2(acc[nt][pt][8 * m + 6], acc[nt][pt][8 * m + 7]);
+                    const unsigned x0 = pack_bf16x2(acc[nt][pt][8 * m + 0], acc[nt][pt][8 * m + 1], floor);
+                    const unsigned x1 = pack_bf16x2(acc[nt][pt][8 * m + 2], acc[nt][pt][8 * m + 3], floor);
+                    const unsigned y0 = pack_bf16x2(acc[nt][pt][8 * m + 4], acc[nt][pt][8 * m + 5], floor);
+                    const unsigned y1 = pack_bf16x2(acc[nt][pt][8 * m + 6], acc[nt][pt][8 * m + 7], floor);
                     auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
                     auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
                     const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 16 * m + 8 * h;
