@@ -71,7 +71,7 @@ constexpr int MH = TH + 2, MW = TW + 2;  // conv1 output (= conv2 input) tile
 constexpr int IH = TH + 4, IW = TW + 4;  // input patch
 constexpr int PS = 80;                   // bytes per staged pixel: 32 bf16 + 16 pad (odd number of 16-B slots)
 constexpr int MPIX = MH * MW;            // 612 mid pixels -> 20 column tiles of 32 (28 idle lanes)
-constexpr int PATCH_BYTES = IH * IW * PS;           // 57600
+constexpr int PATCH_BYTES = 12 * 256 / 4 * PS;     // 61440: 57600 of patch + a pad that absorbs the idle units of the 12th load round
 constexpr int MID_BYTES = 20 * 32 * PS;             // 51200
 constexpr int W_BYTES = 9 * 4 * 32 * 16;            // 18432 per conv
 constexpr int P_UNITS = IH * IW * 4;                // 2880 16-byte units
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
         const int pc = pidx < MPIX ? pidx : MPIX - 1;  // idle lanes read a valid pixel, never write
         const int my = pc / MW, mx = pc % MW;
         paddr[q] = (my * IW + mx) * PS + h * 16;
-        maddr[q] = pidx < MPIX ? pidx * PS + h * 16 : -1;
+        maddr[q] = pidx * PS + h * 16;  // column tiles cover 640 slots: the 28 idle lanes of the last one own real (unused) slots
         myx[q] = (my << 8) | mx;
     }
 
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
     unsigned pf_mask = 0;            // bit i: prefetched unit i lies inside the image (else it is conv padding = 0)
     const bf16_raw *pf_base = p.in;  // patch origin of the tile being prefetched
     int pf_iy0 = 0, pf_ix0 = 0;
+    bool pf_more = true;  // false: there is no next tile, the loads degenerate to re-reading p.in[0..7]
     auto pf_setup = [&](int t) {
         const int b = t / tiles_per_img, tt = t % tiles_per_img;
         pf_iy0 = (tt / p.tiles_x) * TH - 2; pf_ix0 = (tt % p.tiles_x) * TW - 2;
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
     auto pf_load = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int iy = pf_iy0 + (pl_yx[i] >> 8), ix = pf_ix0 + (pl_yx[i] & 255);
-        const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const bool ok = pf_more & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);  // '&': no short-circuit control flow
+        // branch-free (a branch inside a k-step splits the scheduling region and un-interleaves the MFMAs);
         // the load result is not touched here (no s_waitcnt inside the MFMA loop); padding is applied in write_patch
         preg[i] = *reinterpret_cast<const u32x4 *>(ok ? pf_base + pl_off[i] : p.in);
         pf_mask |= ok ? (1u << i) : 0u;
@@ -180,9 +182,8 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
     // one 16-byte unit of the next patch: registers -> LDS (zero outside the image = conv1 padding)
     auto write_patch_unit = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const int u = tid + 256 * i;
-        if (u < P_UNITS)
-            *reinterpret_cast<u32x4 *>(lds_p + (u >> 2) * PS + (u & 3) * 16) = (pf_mask >> i) & 1u ? preg[i] : u32x4{0u, 0u, 0u, 0u};
+        const int u = tid + 256 * i;  // units >= P_UNITS land in the pad behind the patch
+        *reinterpret_cast<u32x4 *>(lds_p + (u >> 2) * PS + (u & 3) * 16) = (pf_mask >> i) & 1u ? preg[i] : u32x4{0u, 0u, 0u, 0u};
     };
 
     int t = blockIdx.x;
@@ -201,19 +202,18 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
         const int oy = prev_oy0 + wave * 4 + q, ox = prev_ox0 + r;
         u32x4 o[2];
         pack_rows16(acc2[q], o);
-        if (oy < p.H && ox < p.W) {
-            bf16_raw *dst = prev_out + ((ptrdiff_t)(wave * 4 + q) * p.W + r) * p.out_cs + 8 * h;
-            *reinterpret_cast<u32x4 *>(dst) = o[0];
-            *reinterpret_cast<u32x4 *>(dst + 16) = o[1];
-        }
+        bf16_raw *dst = prev_out + ((ptrdiff_t)(wave * 4 + q) * p.W + r) * p.out_cs + 8 * h;
+        if (!(prev & (oy < p.H) & (ox < p.W))) dst = p.trash + 8 * h;  // select, not a branch: lanes outside the image (and the
+        *reinterpret_cast<u32x4 *>(dst) = o[0];                        // first tile, which has no predecessor) hit a dummy line
+        *reinterpret_cast<u32x4 *>(dst + 16) = o[1];
     };
 
     for (; t < p.ntiles; t += gridDim.x) {
         const int b = t / tiles_per_img, tt = t % tiles_per_img;
         const int oy0 = (tt / p.tiles_x) * TH, ox0 = (tt % p.tiles_x) * TW;
         const int tn = t + gridDim.x;
-        const bool more = tn < p.ntiles;
-        if (more) pf_setup(tn);
+        pf_more = tn < p.ntiles;
+        pf_setup(pf_more ? tn : t);
         STAMP(0);
 
         // ================= conv1 + bn1 + relu -> mid tile (LDS, bf16) =================
@@ -243,10 +243,10 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
                     __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
                 }
                 if constexpr (st < NPL) {  // one prefetch load per k-step
-                    if (more) pf_load(ic);
+                    pf_load(ic);
                 }
                 if constexpr (st >= 12 && st < 16) {  // the previous tile's output rows leave while the MFMAs run
-                    if (prev) store_rows(st - 12);
+                    store_rows(st - 12);
                 }
 #pragma unroll
                 for (int q = 0; q < 5; ++q)
@@ -286,16 +286,14 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
             for (int q = 0; q < 5; ++q) {
                 const int gy = oy0 - 1 + (myx[q] >> 8), gx = ox0 - 1 + (myx[q] & 255);
                 // conv2 zero-pads the *feature map*: mid pixels outside the image are 0, not conv1(padding)
-                const bool outside = gy < 0 || gy >= p.H || gx < 0 || gx >= p.W;
+                const bool outside = ((unsigned)gy >= (unsigned)p.H) | ((unsigned)gx >= (unsigned)p.W);
                 u32x4 o[2];
                 pack_rows16(acc[q], o);
-                if (maddr[q] >= 0) {
-                    *reinterpret_cast<u32x4 *>(lds_m + maddr[q]) = o[0];
-                    *reinterpret_cast<u32x4 *>(lds_m + maddr[q] + 32) = o[1];
-                    if (outside) {  // only tiles on the image border have such lanes
-                        *reinterpret_cast<u32x4 *>(lds_m + maddr[q]) = u32x4{0u, 0u, 0u, 0u};
-                        *reinterpret_cast<u32x4 *>(lds_m + maddr[q] + 32) = u32x4{0u, 0u, 0u, 0u};
-                    }
+                *reinterpret_cast<u32x4 *>(lds_m + maddr[q]) = o[0];
+                *reinterpret_cast<u32x4 *>(lds_m + maddr[q] + 32) = o[1];
+                if (outside) {  // only tiles on the image border have such lanes
+                    *reinterpret_cast<u32x4 *>(lds_m + maddr[q]) = u32x4{0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4 *>(lds_m + maddr[q] + 32) = u32x4{0u, 0u, 0u, 0u};
                 }
             }
         }
@@ -322,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
                     __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
                 }
                 if constexpr (st >= 2 && st - 2 < NPL) {
-                    if (more) write_patch_unit(std::integral_constant<int, st - 2>{});
+                    write_patch_unit(std::integral_constant<int, st - 2>{});
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 }
 #pragma unroll
@@ -341,16 +339,21 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
         STAMP(6);
         STAMP(7);
     }
-    if (prev)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) store_rows(q);
+    for (int q = 0; q < 4; ++q) store_rows(q);
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
 #endif
 }
 
+static bf16_raw *g_trash = nullptr;  // 64 B every lane may scribble on (stores of lanes outside the image)
+
 hipError_t bb_fused_init()
 {
+    if (!g_trash) {
+        hipError_t e = hipMalloc((void **)&g_trash, 256);
+        if (e != hipSuccess) return e;
+    }
     return hipFuncSetAttribute(reinterpret_cast<const void *>(bb_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)bb_fused_lds_bytes());
 }
@@ -360,6 +363,7 @@ hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s)
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    p.trash = g_trash;
     const int grid = p.ntiles < num_cus ? p.ntiles : num_cus;
     hipLaunchKernelGGL(bb_fused_kernel, dim3(grid), dim3(256), bb_fused_lds_bytes(), s, p);
     return hipGetLastError();

@@ -188,53 +188,59 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
                 }
     }
 
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    // ---- MFMA over taps x 16-channel k-steps of one chunk.  LDS fragment reads run one k-step ahead
+    //      (sched_group_barrier pins the order) and, when `more_c`, the next chunk's global loads are spread over the
+    //      k-steps, LPS per step: issued in a burst they back-pressure the CU's load path (~10 B/cycle) and the MFMAs wait
+    //      behind them.  `more_c` is a compile-time flag (the last chunk is a separate copy of the body): a run-time
+    //      branch inside a k-step splits the scheduling region and the LDS reads / loads no longer interleave with the MFMAs.
+    auto mfma_chunk = [&](auto more_c, int chunk) {
+        constexpr bool more = decltype(more_c)::value;
+        u32x4 fa[2][NT], fb[2][PT];
+        auto ldf = [&](int st, int buf) {
+            const int tap = st / (KC / 16), kk = st % (KC / 16), ky = tap / KS, kx = tap % KS;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int unit = ((tap * C8 + kk * 2 + h) * COUT_T) + (wc * NT + nt) * 32 + r;
+                fa[buf][nt] = *reinterpret_cast<const u32x4 *>(lds_w + unit * 16);
+            }
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int row = (wp * PT + pt) * RPT + dy;
+                const int addr = ((row * S + ky) * PW + dx * S + kx) * PS + kk * 32 + h * 16;
+                fb[buf][pt] = *reinterpret_cast<const u32x4 *>(lds_p + addr);
+            }
+        };
+        ldf(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + PT, 0);
+        static_for<NSTEP>([&](auto ic) {
+            constexpr int st = decltype(ic)::value;
+            if (st + 1 < NSTEP) {
+                ldf(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, NT + PT, 0);
+            }
+            if constexpr (more)
+                static_for<LPS>([&](auto lc) {
+                    load_unit(std::integral_constant<int, st * LPS + decltype(lc)::value>{}, chunk + 1);
+                });
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st & 1][nt]),
+                                                                          __builtin_bit_cast(bf16x8, fb[st & 1][pt]),
+                                                                          acc[nt][pt], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, NT * PT, 0);
+        });
+    };
+    for (int chunk = 0; chunk + 1 < nchunks; ++chunk) {
         write_lds();
         __syncthreads();
-        const bool more = chunk + 1 < nchunks;
-        // ---- MFMA over taps x 16-channel k-steps.  LDS fragment reads run one k-step ahead (sched_group_barrier pins
-        //      the order) and the next chunk's global loads are spread over the k-steps, LPS per step: issued in a
-        //      burst they back-pressure the CU's load path (~10 B/cycle) and the MFMAs wait behind them.
-        {
-            u32x4 fa[2][NT], fb[2][PT];
-            auto ldf = [&](int st, int buf) {
-                const int tap = st / (KC / 16), kk = st % (KC / 16), ky = tap / KS, kx = tap % KS;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int unit = ((tap * C8 + kk * 2 + h) * COUT_T) + (wc * NT + nt) * 32 + r;
-                    fa[buf][nt] = *reinterpret_cast<const u32x4 *>(lds_w + unit * 16);
-                }
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt) {
-                    const int row = (wp * PT + pt) * RPT + dy;
-                    const int addr = ((row * S + ky) * PW + dx * S + kx) * PS + kk * 32 + h * 16;
-                    fb[buf][pt] = *reinterpret_cast<const u32x4 *>(lds_p + addr);
-                }
-            };
-            ldf(0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, NT + PT, 0);
-            static_for<NSTEP>([&](auto ic) {
-                constexpr int st = decltype(ic)::value;
-                if (st + 1 < NSTEP) {
-                    ldf(st + 1, (st + 1) & 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, NT + PT, 0);
-                }
-                if (more)
-                    static_for<LPS>([&](auto lc) {
-                        load_unit(std::integral_constant<int, st * LPS + decltype(lc)::value>{}, chunk + 1);
-                    });
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st & 1][nt]),
-                                                                              __builtin_bit_cast(bf16x8, fb[st & 1][pt]),
-                                                                              acc[nt][pt], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x8, NT * PT, 0);
-            });
-        }
-        if (more) __syncthreads();  // every wave is done reading this chunk (LDS is rewritten next)
+        mfma_chunk(std::true_type{}, chunk);
+        __syncthreads();  // every wave is done reading this chunk (LDS is rewritten next)
     }
+    write_lds();
+    __syncthreads();
+    mfma_chunk(std::false_type{}, nchunks - 1);
 
     // ---- epilogue: (ReLU) -> fp32 NCHW directly, or bf16 NHWC with the half-waves paired by v_permlane32_swap so
     //      that every lane stores 16 contiguous bytes (couts 16m+8h..+7 of its pixel) straight from registers.

@@ -64,6 +64,7 @@ struct BBParams {
     const float *b1, *b2;            // [32]
     int B, H, W;
     int tiles_x, tiles_y, ntiles;    // filled by bb_fused_launch
+    bf16_raw *trash;                 // filled by bb_fused_launch: dummy line for the stores of lanes outside the image
     unsigned long long *stamps;      // diagnostic build (-DHH_STAMP) only
     unsigned long long *clk;         // optional {min start, max end} of the launch in wall_clock64() ticks
 };
