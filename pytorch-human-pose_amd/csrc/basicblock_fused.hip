@@ -71,11 +71,12 @@ constexpr int MH = TH + 2, MW = TW + 2;  // conv1 output (= conv2 input) tile
 constexpr int IH = TH + 4, IW = TW + 4;  // input patch
 constexpr int PS = 80;                   // bytes per staged pixel: 32 bf16 + 16 pad (odd number of 16-B slots)
 constexpr int MPIX = MH * MW;            // 612 mid pixels -> 20 column tiles of 32 (28 idle lanes)
-constexpr int PATCH_BYTES = 12 * 256 / 4 * PS;     // 61440: 57600 of patch + a pad that absorbs the idle units of the 12th load round
+constexpr int NTHR = 512;                // 8 waves: two per SIMD, so one wave's VALU / LDS / store work hides behind the other's MFMAs
+constexpr int P_UNITS = IH * IW * 4;                // 2880 16-byte units
+constexpr int NPL = (P_UNITS + NTHR - 1) / NTHR;    // 6 prefetch loads per thread
+constexpr int PATCH_BYTES = NPL * NTHR / 4 * PS;    // 61440: 57600 of patch + a pad that absorbs the idle units of the last load round
 constexpr int MID_BYTES = 20 * 32 * PS;             // 51200
 constexpr int W_BYTES = 9 * 4 * 32 * 16;            // 18432 per conv
-constexpr int P_UNITS = IH * IW * 4;                // 2880 16-byte units
-constexpr int NPL = (P_UNITS + 255) / 256;          // 12
 constexpr int W_UNITS = W_BYTES / 16;               // 1152
 }  // namespace
 
@@ -85,16 +86,17 @@ constexpr int W_UNITS = W_BYTES / 16;               // 1152
 #define STAMP(i)
 #endif
 
-size_t bb_fused_lds_bytes() { return PATCH_BYTES + MID_BYTES + 2 * W_BYTES; }
+size_t bb_fused_lds_bytes() { return PATCH_BYTES + MID_BYTES + 2 * W_BYTES + 256; }
 
-__global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
+__global__ __launch_bounds__(NTHR, 1) void bb_fused_kernel(const BBParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *lds_p = smem;
     char *lds_m = smem + PATCH_BYTES;
     char *lds_w1 = lds_m + MID_BYTES;
     char *lds_w2 = lds_w1 + W_BYTES;
-
+    float *lds_b = reinterpret_cast<float *>(lds_w2 + W_BYTES);  // [2][32] folded BN shifts (re-read at every accumulator init:
+                                                                 // 32 live VGPRs would push the 256-register budget into scratch)
     const int tid = threadIdx.x;
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0) atomicMin(p.clk, wall_clock64());
@@ -103,16 +105,11 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
     const int r = lane & 31, h = lane >> 5;
 
     // ---- both weight sets: loaded once per workgroup
-    for (int u = tid; u < W_UNITS; u += 256) {
+    for (int u = tid; u < W_UNITS; u += NTHR) {
         reinterpret_cast<u32x4 *>(lds_w1)[u] = reinterpret_cast<const u32x4 *>(p.w1)[u];
         reinterpret_cast<u32x4 *>(lds_w2)[u] = reinterpret_cast<const u32x4 *>(p.w2)[u];
     }
-    float4 b1v[4], b2v[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        b1v[g] = *reinterpret_cast<const float4 *>(p.b1 + 8 * g + 4 * h);
-        b2v[g] = *reinterpret_cast<const float4 *>(p.b2 + 8 * g + 4 * h);
-    }
+    if (tid < 32) { lds_b[tid] = p.b1[tid]; lds_b[32 + tid] = p.b2[tid]; }
     // identity A fragments (rows = couts, k = cin): frag kk has A[r][k] = 1 where 16*kk + k == r
     u32x4 ident[2];
 #pragma unroll
@@ -128,18 +125,21 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
     int pl_off[NPL], pl_yx[NPL];  // prefetch unit i: element offset from the tile's patch origin, (py << 8) | px
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-        const int u = tid + 256 * i, pix = u >> 2, py = pix / IW, px = pix % IW;
+        const int u = tid + NTHR * i, pix = u >> 2, py = pix / IW, px = pix % IW;
         pl_off[i] = (py * p.W + px) * p.in_cs + (u & 3) * 8;
         pl_yx[i] = u < P_UNITS ? ((py << 8) | px) : (255 << 8);  // py = 255 -> never inside
     }
-    int paddr[5], maddr[5], myx[5];  // conv1 column tiles of this wave: patch read base, mid write base, (my << 8) | mx
+    // conv1 column tiles: waves 0-3 own 3 each (tiles 3w..3w+2), waves 4-7 own 2 each (12+2(w-4)..): waves w and w+4 share a
+    // SIMD, so every SIMD carries 5 of the 20 tiles.  conv2: wave w owns output rows 2w, 2w+1.
+    const int q0 = wave < 4 ? wave * 3 : 12 + (wave - 4) * 2;
+    int paddr[3], maddr[3], myx[3];  // patch read base, mid write base, (my << 8) | mx   (entry 2 unused by waves 4-7)
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        const int pidx = (wave * 5 + q) * 32 + r;
-        const int pc = pidx < MPIX ? pidx : MPIX - 1;  // idle lanes read a valid pixel, never write
+    for (int q = 0; q < 3; ++q) {
+        const int pidx = (q0 + q) * 32 + r;
+        const int pc = pidx < MPIX ? pidx : MPIX - 1;  // idle lanes read a valid pixel and own a real (unused) mid slot
         const int my = pc / MW, mx = pc % MW;
         paddr[q] = (my * IW + mx) * PS + h * 16;
-        maddr[q] = pidx * PS + h * 16;  // column tiles cover 640 slots: the 28 idle lanes of the last one own real (unused) slots
+        maddr[q] = pidx * PS + h * 16;
         myx[q] = (my << 8) | mx;
     }
 
@@ -160,51 +160,38 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
         const int iy = pf_iy0 + (pl_yx[i] >> 8), ix = pf_ix0 + (pl_yx[i] & 255);
         const bool ok = pf_more & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);  // '&': no short-circuit control flow
         // branch-free (a branch inside a k-step splits the scheduling region and un-interleaves the MFMAs);
-        // the load result is not touched here (no s_waitcnt inside the MFMA loop); padding is applied in write_patch
+        // the load result is not touched here (no s_waitcnt inside the MFMA loop); padding is applied when it goes to LDS
         preg[i] = *reinterpret_cast<const u32x4 *>(ok ? pf_base + pl_off[i] : p.in);
         pf_mask |= ok ? (1u << i) : 0u;
     };
-    auto write_patch = [&]() {
-        static_for<NPL>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const int u = tid + 256 * i;
-            if (u < P_UNITS)
-                *reinterpret_cast<u32x4 *>(lds_p + (u >> 2) * PS + (u & 3) * 16) =
-                    (pf_mask >> i) & 1u ? preg[i] : u32x4{0u, 0u, 0u, 0u};  // zero outside the image = conv1 padding
-        });
+    // one 16-byte unit of the next patch: registers -> LDS (zero outside the image = conv1 padding)
+    auto write_patch_unit = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int u = tid + NTHR * i;  // units >= P_UNITS land in the pad behind the patch
+        *reinterpret_cast<u32x4 *>(lds_p + (u >> 2) * PS + (u & 3) * 16) = (pf_mask >> i) & 1u ? preg[i] : u32x4{0u, 0u, 0u, 0u};
     };
-
     // Workgroup barrier that waits for LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would stall every
     // wave until the next tile's prefetch loads (issued during conv1, consumed during conv2) and the previous tile's
     // output stores have completed.
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    // one 16-byte unit of the next patch: registers -> LDS (zero outside the image = conv1 padding)
-    auto write_patch_unit = [&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const int u = tid + 256 * i;  // units >= P_UNITS land in the pad behind the patch
-        *reinterpret_cast<u32x4 *>(lds_p + (u >> 2) * PS + (u & 3) * 16) = (pf_mask >> i) & 1u ? preg[i] : u32x4{0u, 0u, 0u, 0u};
-    };
-
     int t = blockIdx.x;
-    if (t < p.ntiles) {
-        pf_setup(t);
-        static_for<NPL>(pf_load);
-    }
-    write_patch();
+    pf_setup(t);
+    static_for<NPL>(pf_load);
+    static_for<NPL>(write_patch_unit);
     __syncthreads();
 
-    f32x16 acc2[4];             // conv2 accumulators; the finished tile is stored during the NEXT tile's conv1
+    f32x16 acc2[2];              // conv2 accumulators; the finished tile is stored during the NEXT tile's conv1
     bool prev = false;
     bf16_raw *prev_out = p.out;  // + (oy0 * W + ox0) * out_cs of the finished tile
     int prev_oy0 = 0, prev_ox0 = 0;
     auto store_rows = [&](int q) {  // ReLU, bf16, 16 contiguous bytes per lane straight to HBM
-        const int oy = prev_oy0 + wave * 4 + q, ox = prev_ox0 + r;
+        const int oy = prev_oy0 + wave * 2 + q, ox = prev_ox0 + r;
         u32x4 o[2];
         pack_rows16(acc2[q], o);
-        bf16_raw *dst = prev_out + ((ptrdiff_t)(wave * 4 + q) * p.W + r) * p.out_cs + 8 * h;
+        bf16_raw *dst = prev_out + ((ptrdiff_t)(wave * 2 + q) * p.W + r) * p.out_cs + 8 * h;
         if (!(prev & (oy < p.H) & (ox < p.W))) dst = p.trash + 8 * h;  // select, not a branch: lanes outside the image (and the
-        *reinterpret_cast<u32x4 *>(dst) = o[0];                        // first tile, which has no predecessor) hit a dummy line
+        *reinterpret_cast<u32x4 *>(dst) = o[0];                         // first tile, which has no predecessor) hit a dummy line
         *reinterpret_cast<u32x4 *>(dst + 16) = o[1];
     };
 
@@ -217,73 +204,72 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
         STAMP(0);
 
         // ================= conv1 + bn1 + relu -> mid tile (LDS, bf16) =================
-        {
-            f32x16 acc[5];
+        auto conv1_phase = [&](auto nqc) {
+            constexpr int NQ = decltype(nqc)::value;
+            f32x16 acc[NQ];
 #pragma unroll
-            for (int q = 0; q < 5; ++q)
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4 *>(lds_b + 8 * g + 4 * h);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    acc[q][4 * g + 0] = b1v[g].x; acc[q][4 * g + 1] = b1v[g].y;
-                    acc[q][4 * g + 2] = b1v[g].z; acc[q][4 * g + 3] = b1v[g].w;
+                for (int q = 0; q < NQ; ++q) {
+                    acc[q][4 * g + 0] = bv.x; acc[q][4 * g + 1] = bv.y; acc[q][4 * g + 2] = bv.z; acc[q][4 * g + 3] = bv.w;
                 }
-            u32x4 fa[2], fb[2][5];
+            }
+            u32x4 fa[2], fb[2][NQ];
             auto ld1 = [&](int st, int buf) {
                 const int tap = st >> 1, kk = st & 1, ky = tap / 3, kx = tap % 3;
                 fa[buf] = *reinterpret_cast<const u32x4 *>(lds_w1 + ((tap * 4 + kk * 2 + h) * 32 + r) * 16);
 #pragma unroll
-                for (int q = 0; q < 5; ++q)
+                for (int q = 0; q < NQ; ++q)
                     fb[buf][q] = *reinterpret_cast<const u32x4 *>(lds_p + paddr[q] + (ky * IW + kx) * PS + kk * 32);
             };
             ld1(0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NQ + 1, 0);
             static_for<18>([&](auto ic) {
                 constexpr int st = decltype(ic)::value;
                 if (st + 1 < 18) {
                     ld1(st + 1, (st + 1) & 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NQ + 1, 0);
                 }
-                if constexpr (st < NPL) {  // one prefetch load per k-step
-                    pf_load(ic);
-                }
-                if constexpr (st >= 12 && st < 16) {  // the previous tile's output rows leave while the MFMAs run
-                    store_rows(st - 12);
-                }
+                if constexpr (st < NPL) pf_load(ic);                     // one prefetch load per k-step
+                if constexpr (st >= 12 && st < 14) store_rows(st - 12);  // the previous tile's rows leave while the MFMAs run
 #pragma unroll
-                for (int q = 0; q < 5; ++q)
+                for (int q = 0; q < NQ; ++q)
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st & 1]),
                                                                      __builtin_bit_cast(bf16x8, fb[st & 1][q]), acc[q], 0, 0, 0);
-                if constexpr (st >= 12 && st < 16) {
-                    // the pack/store VALU work only overlaps the matrix pipe when it sits BETWEEN the MFMAs (in-order issue)
+                if constexpr (st >= 12 && st < 14) {
+                    // VALU work only overlaps this wave's own MFMAs when it sits BETWEEN them (in-order issue)
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) {
+                    for (int q = 0; q < NQ; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x2, 36 / NQ, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x40, 2, 0);
                 } else {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x8, NQ, 0);
                 }
             });
             STAMP(1);
             // conv2's accumulators start as bn2 shift + residual: the centre of the input patch times an identity A
             // fragment (exact: x * 1.0 in fp32), issued now because the patch buffer is recycled during conv2
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4 *>(lds_b + 32 + 8 * g + 4 * h);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    acc2[q][4 * g + 0] = b2v[g].x; acc2[q][4 * g + 1] = b2v[g].y;
-                    acc2[q][4 * g + 2] = b2v[g].z; acc2[q][4 * g + 3] = b2v[g].w;
+                for (int q = 0; q < 2; ++q) {
+                    acc2[q][4 * g + 0] = bv.x; acc2[q][4 * g + 1] = bv.y; acc2[q][4 * g + 2] = bv.z; acc2[q][4 * g + 3] = bv.w;
                 }
+            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u32x4 x = *reinterpret_cast<const u32x4 *>(lds_p + ((wave * 4 + q + 2) * IW + r + 2) * PS + kk * 32 + h * 16);
+                for (int q = 0; q < 2; ++q) {
+                    const u32x4 x = *reinterpret_cast<const u32x4 *>(lds_p + ((wave * 2 + q + 2) * IW + r + 2) * PS + kk * 32 + h * 16);
                     acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ident[kk]), __builtin_bit_cast(bf16x8, x),
                                                                       acc2[q], 0, 0, 0);
                 }
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int gy = oy0 - 1 + (myx[q] >> 8), gx = ox0 - 1 + (myx[q] & 255);
                 // conv2 zero-pads the *feature map*: mid pixels outside the image are 0, not conv1(padding)
                 const bool outside = ((unsigned)gy >= (unsigned)p.H) | ((unsigned)gx >= (unsigned)p.W);
@@ -296,38 +282,50 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
                     *reinterpret_cast<u32x4 *>(lds_m + maddr[q] + 32) = u32x4{0u, 0u, 0u, 0u};
                 }
             }
-        }
+        };
+        if (wave < 4) conv1_phase(std::integral_constant<int, 3>{});
+        else conv1_phase(std::integral_constant<int, 2>{});
         STAMP(2);
         lds_barrier();  // mid tile visible; every wave is done reading the patch
         STAMP(3);
 
         // ================= conv2 + bn2 (+ residual already in acc2); the next patch goes to LDS meanwhile =================
+        // LDS read bandwidth (128 B/clk/CU, 8 clk per ds_read_b128) bounds this kernel, so every pixel fragment is read
+        // once per (kx, k-half) and used for all the output rows it feeds: mid row i = out row j + ky.  Per (kx, kk):
+        // 3 weight fragments (ky = 0..2) + 4 mid rows -> 6 MFMAs (was 9 reads per 6 MFMAs).
         {
-            u32x4 fa[2], fb[2][4];
-            auto ld2 = [&](int st, int buf) {
-                const int tap = st >> 1, kk = st & 1, ky = tap / 3, kx = tap % 3;
-                fa[buf] = *reinterpret_cast<const u32x4 *>(lds_w2 + ((tap * 4 + kk * 2 + h) * 32 + r) * 16);
+            u32x4 fa[2][3], fb[2];
+            auto lda = [&](int c, int buf) {  // c = kx * 2 + kk
+                const int kx = c >> 1, kk = c & 1;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    fb[buf][q] = *reinterpret_cast<const u32x4 *>(lds_m + ((wave * 4 + q + ky) * MW + r + kx) * PS + kk * 32 + h * 16);
+                for (int ky = 0; ky < 3; ++ky)
+                    fa[buf][ky] = *reinterpret_cast<const u32x4 *>(lds_w2 + (((ky * 3 + kx) * 4 + kk * 2 + h) * 32 + r) * 16);
             };
-            ld2(0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-            static_for<18>([&](auto ic) {
-                constexpr int st = decltype(ic)::value;
-                if (st + 1 < 18) {
-                    ld2(st + 1, (st + 1) & 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-                }
-                if constexpr (st >= 2 && st - 2 < NPL) {
-                    write_patch_unit(std::integral_constant<int, st - 2>{});
+            auto ldb = [&](int s, int buf) {  // s = c * 4 + i
+                const int c = s >> 2, i = s & 3, kx = c >> 1, kk = c & 1;
+                fb[buf] = *reinterpret_cast<const u32x4 *>(lds_m + ((wave * 2 + i) * MW + r + kx) * PS + kk * 32 + h * 16);
+            };
+            lda(0, 0);
+            ldb(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            static_for<24>([&](auto sc) {
+                constexpr int s = decltype(sc)::value, c = s >> 2, i = s & 3;
+                constexpr int nread = (s + 1 < 24 ? 1 : 0) + ((i == 0 && c + 1 < 6) ? 3 : 0);
+                if constexpr (s + 1 < 24) ldb(s + 1, (s + 1) & 1);
+                if constexpr (i == 0 && c + 1 < 6) lda(c + 1, (c + 1) & 1);  // next combo's weights, a whole combo ahead
+                if constexpr (nread > 0) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);
+                if constexpr (s >= 2 && s - 2 < NPL) {
+                    write_patch_unit(std::integral_constant<int, s - 2>{});
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[st & 1]),
-                                                                      __builtin_bit_cast(bf16x8, fb[st & 1][q]), acc2[q], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+                constexpr int nm = (i == 0 || i == 3) ? 1 : 2;
+                static_for<3>([&](auto kyc) {
+                    constexpr int ky = decltype(kyc)::value, j = i - ky;
+                    if constexpr (j >= 0 && j < 2)
+                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[c & 1][ky]),
+                                                                          __builtin_bit_cast(bf16x8, fb[s & 1]), acc2[j], 0, 0, 0);
+                });
+                __builtin_amdgcn_sched_group_barrier(0x8, nm, 0);
             });
         }
         STAMP(4);
@@ -340,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void bb_fused_kernel(const BBParams p)
         STAMP(7);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) store_rows(q);
+    for (int q = 0; q < 2; ++q) store_rows(q);
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
 #endif
@@ -365,6 +363,6 @@ hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s)
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     p.trash = g_trash;
     const int grid = p.ntiles < num_cus ? p.ntiles : num_cus;
-    hipLaunchKernelGGL(bb_fused_kernel, dim3(grid), dim3(256), bb_fused_lds_bytes(), s, p);
+    hipLaunchKernelGGL(bb_fused_kernel, dim3(grid), dim3(NTHR), bb_fused_lds_bytes(), s, p);
     return hipGetLastError();
 }
