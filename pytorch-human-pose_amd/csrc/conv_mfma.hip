@@ -195,6 +195,51 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     //      branch inside a k-step splits the scheduling region and the LDS reads / loads no longer interleave with the MFMAs.
     auto mfma_chunk = [&](auto more_c, int chunk) {
         constexpr bool more = decltype(more_c)::value;
+        if constexpr (KS == 3 && S == 1 && TW == 32) {
+            // LDS read bandwidth (8 clk per ds_read_b128, 128 B/clk/CU) is as scarce as MFMA issue here, so a pixel-row
+            // fragment is read once per (kx, k-step) and used for every output row it feeds (patch row i = out row + ky):
+            // per (kx, kk) NT*3 weight fragments + PT+2 rows feed NT*PT*3 MFMAs, instead of one read per MFMA operand pair.
+            constexpr int NC = 3 * (KC / 16), NR = PT + 2, NS = NC * NR;
+            constexpr int LPR = (NL + NS - 1) / NS;
+            u32x4 fa[2][3][NT], fb[2];
+            auto lda = [&](int c, int buf) {
+                const int kx = c / (KC / 16), kk = c % (KC / 16);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int unit = (((ky * 3 + kx) * C8 + kk * 2 + h) * COUT_T) + (wc * NT + nt) * 32 + r;
+                        fa[buf][ky][nt] = *reinterpret_cast<const u32x4 *>(lds_w + unit * 16);
+                    }
+            };
+            auto ldb = [&](int s, int buf) {
+                const int c = s / NR, i = s % NR, kx = c / (KC / 16), kk = c % (KC / 16);
+                fb[buf] = *reinterpret_cast<const u32x4 *>(lds_p + ((wp * PT + i) * PW + dx + kx) * PS + kk * 32 + h * 16);
+            };
+            lda(0, 0);
+            ldb(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3 * NT + 1, 0);
+            static_for<NS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value, c = s / NR, i = s % NR;
+                constexpr int nread = (s + 1 < NS ? 1 : 0) + ((i == 0 && c + 1 < NC) ? 3 * NT : 0);
+                if constexpr (s + 1 < NS) ldb(s + 1, (s + 1) & 1);
+                if constexpr (i == 0 && c + 1 < NC) lda(c + 1, (c + 1) & 1);  // next combo's weights, a whole combo ahead
+                if constexpr (nread > 0) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);
+                if constexpr (more)
+                    static_for<LPR>([&](auto lc) { load_unit(std::integral_constant<int, s * LPR + decltype(lc)::value>{}, chunk + 1); });
+                constexpr int lo = i - (PT - 1) > 0 ? i - (PT - 1) : 0, hi = i < 2 ? i : 2;  // ky range with 0 <= i - ky < PT
+                static_for<3>([&](auto kyc) {
+                    constexpr int ky = decltype(kyc)::value, pt = i - ky;
+                    if constexpr (pt >= 0 && pt < PT)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[c & 1][ky][nt]),
+                                                                                  __builtin_bit_cast(bf16x8, fb[s & 1]), acc[nt][pt], 0, 0, 0);
+                });
+                __builtin_amdgcn_sched_group_barrier(0x8, NT * (hi - lo + 1), 0);
+            });
+            return;
+        }
         u32x4 fa[2][NT], fb[2][PT];
         auto ldf = [&](int st, int buf) {
             const int tap = st / (KC / 16), kk = st % (KC / 16), ky = tap / KS, kx = tap % KS;
