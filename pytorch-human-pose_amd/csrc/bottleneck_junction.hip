@@ -1,0 +1,198 @@
+// Junction between two stage-0 Bottlenecks (/root/reference/src/keypoints/architectures/hrnet.py:29-74):
+//   y  = relu(bn3(conv3_1x1(t2)) + residual)          residual = previous y (256 ch), or bn_d(downsample_1x1(x)) for unit 0
+//   t1 = relu(bn1'(conv1'_1x1(y)))                    first conv of the NEXT unit (optional)
+// in ONE pass over the pixels.  Both convs are 1x1, so a pixel's 256 outputs never leave the wave that made them: the
+// packed bf16 accumulators of the first GEMM (what goes to HBM as y) ARE the B fragments of the second -- the C layout
+// after v_permlane32_swap is 8 consecutive channels per lane, exactly one 16-channel k-step per (cout tile, half).
+// Why: stage 0 moves 256-channel tensors at 128x128 and is HBM bound; unfused, y is written by conv3 and read again by
+// the next conv1 (268 MB at B=32, three times), and unit 0 round-trips the downsample result (2 x 268 MB).
+// Pixel fragments of t2 / x are loaded from HBM straight into the MFMA B layout (16 B per lane), weights sit in LDS.
+#include "kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+__device__ __forceinline__ unsigned pack_relu_bf16x2(float a, float b)
+{
+    f32x2 f = {a, b};
+    const i16x2 v = __builtin_bit_cast(i16x2, __builtin_convertvector(f, bf16x2));
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, i16x2{0, 0}));  // ReLU on the packed pair
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// acc (32 couts of this lane's pixel, MFMA C layout) -> for m = 0,1 the 16 bytes of couts 16m+8h..+7 (ReLU, bf16)
+__device__ __forceinline__ void pack_rows16(const f32x16 &acc, u32x4 out[2])
+{
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        unsigned x0 = pack_relu_bf16x2(acc[8 * m + 0], acc[8 * m + 1]), x1 = pack_relu_bf16x2(acc[8 * m + 2], acc[8 * m + 3]);
+        unsigned y0 = pack_relu_bf16x2(acc[8 * m + 4], acc[8 * m + 5]), y1 = pack_relu_bf16x2(acc[8 * m + 6], acc[8 * m + 7]);
+        auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+        out[m] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+    }
+}
+// inverse for the residual: 16 bytes (couts 16m+8h..+7) per m -> added onto the accumulator in C layout
+__device__ __forceinline__ void add_rows16(f32x16 &acc, const u32x4 v[2])
+{
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        auto s0 = __builtin_amdgcn_permlane32_swap(v[m][0], v[m][2], false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(v[m][1], v[m][3], false, false);
+        acc[8 * m + 0] += bf16_lo(s0[0]); acc[8 * m + 1] += bf16_hi(s0[0]);
+        acc[8 * m + 2] += bf16_lo(s1[0]); acc[8 * m + 3] += bf16_hi(s1[0]);
+        acc[8 * m + 4] += bf16_lo(s0[1]); acc[8 * m + 5] += bf16_hi(s0[1]);
+        acc[8 * m + 6] += bf16_lo(s1[1]); acc[8 * m + 7] += bf16_hi(s1[1]);
+    }
+}
+constexpr int W3_BYTES = 256 * 64 * 2;  // conv3 / downsample: packed [cout group 4][chunk 2][c8 4][64][8] (conv_mfma family, NT = 2)
+constexpr int W1_BYTES = 64 * 256 * 2;  // next conv1: packed [chunk 8][c8 4][64][8]
+}  // namespace
+
+// HAS_DS: unit 0 (residual = downsample conv of x, folded in as 4 more k-steps); otherwise residual = p.res (256 ch)
+template <bool HAS_DS>
+__global__ __launch_bounds__(256, 2) void junction_kernel(const JuncParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *lds_w3 = smem;
+    char *lds_wd = smem + W3_BYTES;                          // only when HAS_DS
+    char *lds_w1 = smem + (HAS_DS ? 2 : 1) * W3_BYTES;
+    float *lds_b = reinterpret_cast<float *>(lds_w1 + W1_BYTES);  // [256] y shift, [64] t1 shift
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+#ifndef HH_NO_CLK
+    if (p.clk && tid == 0) atomicMin(p.clk, wall_clock64());
+#endif
+    for (int u = tid; u < W3_BYTES / 16; u += 256) {
+        reinterpret_cast<u32x4 *>(lds_w3)[u] = reinterpret_cast<const u32x4 *>(p.w3)[u];
+        if (HAS_DS) reinterpret_cast<u32x4 *>(lds_wd)[u] = reinterpret_cast<const u32x4 *>(p.wd)[u];
+        if (p.w1) reinterpret_cast<u32x4 *>(lds_w1)[u] = reinterpret_cast<const u32x4 *>(p.w1)[u];
+    }
+    lds_b[tid] = p.b3[tid] + (HAS_DS ? p.bd[tid] : 0.f);
+    if (tid < 64) lds_b[256 + tid] = p.w1 ? p.b1[tid] : 0.f;
+    __syncthreads();
+
+    const int ngroups = (p.npix + 127) / 128;
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int pix = g * 128 + wave * 32 + r;
+        const bool valid = pix < p.npix;
+        const size_t px = valid ? pix : 0;
+        // ---- loads: pixel fragments (B operands) first
+        u32x4 bt[4], bx[HAS_DS ? 4 : 1];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bt[s] = *reinterpret_cast<const u32x4 *>(p.t2 + px * p.t2_cs + s * 16 + h * 8);
+            if (HAS_DS) bx[s] = *reinterpret_cast<const u32x4 *>(p.x + px * p.x_cs + s * 16 + h * 8);
+        }
+        // ---- GEMM 1 in two halves of 128 output channels (64 accumulator registers live at a time):
+        //      y[256] = W3 t2 (+ Wd x) + shift (+ residual), ReLU, bf16; y leaves for HBM and stays in registers (yf) as the
+        //      B operand of the next GEMM
+        u32x4 yf[8][2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x4 rv[HAS_DS ? 1 : 4][2];
+            if (!HAS_DS)
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        rv[mm][q] = *reinterpret_cast<const u32x4 *>(p.res + px * p.res_cs + (half * 4 + mm) * 32 + q * 16 + h * 8);
+            f32x16 acc[4];
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(lds_b + (half * 4 + mm) * 32 + 8 * gq + 4 * h);
+                    acc[mm][4 * gq + 0] = bv.x; acc[mm][4 * gq + 1] = bv.y; acc[mm][4 * gq + 2] = bv.z; acc[mm][4 * gq + 3] = bv.w;
+                }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) {
+                    const int m = half * 4 + mm;
+                    const int unit = (((m >> 1) * 2 + (s >> 1)) * 4 + (s & 1) * 2 + h) * 64 + (m & 1) * 32 + r;
+                    const u32x4 a = *reinterpret_cast<const u32x4 *>(lds_w3 + unit * 16);
+                    acc[mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bt[s]), acc[mm], 0, 0, 0);
+                    if (HAS_DS) {
+                        const u32x4 ad = *reinterpret_cast<const u32x4 *>(lds_wd + unit * 16);
+                        acc[mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ad), __builtin_bit_cast(bf16x8, bx[s]), acc[mm], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the weight-fragment reads of later k-steps from piling up in registers
+            }
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                const int m = half * 4 + mm;
+                if (!HAS_DS) add_rows16(acc[mm], rv[mm]);
+                pack_rows16(acc[mm], yf[m]);
+                if (valid) {
+                    bf16_raw *dst = p.y + (size_t)pix * p.y_cs + m * 32 + h * 8;
+                    *reinterpret_cast<u32x4 *>(dst) = yf[m][0];
+                    *reinterpret_cast<u32x4 *>(dst + 16) = yf[m][1];
+                }
+            }
+        }
+        if (!p.w1) continue;
+        // ---- GEMM 2: t1[64] = W1' y + shift, ReLU
+        f32x16 acc2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 bv = *reinterpret_cast<const float4 *>(lds_b + 256 + t * 32 + 8 * gq + 4 * h);
+                acc2[t][4 * gq + 0] = bv.x; acc2[t][4 * gq + 1] = bv.y; acc2[t][4 * gq + 2] = bv.z; acc2[t][4 * gq + 3] = bv.w;
+            }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int unit = ((s >> 1) * 4 + (s & 1) * 2 + h) * 64 + t * 32 + r;
+                const u32x4 a = *reinterpret_cast<const u32x4 *>(lds_w1 + unit * 16);
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, yf[s >> 1][s & 1]),
+                                                                 acc2[t], 0, 0, 0);
+            }
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 o[2];
+            pack_rows16(acc2[t], o);
+            if (valid) {
+                bf16_raw *dst = p.t1 + (size_t)pix * p.t1_cs + t * 32 + h * 8;
+                *reinterpret_cast<u32x4 *>(dst) = o[0];
+                *reinterpret_cast<u32x4 *>(dst + 16) = o[1];
+            }
+        }
+    }
+#ifndef HH_NO_CLK
+    if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
+#endif
+}
+
+static size_t junc_lds(bool ds) { return (ds ? 2 : 1) * W3_BYTES + W1_BYTES + 320 * 4; }
+
+hipError_t junction_init()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(junction_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)junc_lds(true));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(junction_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)junc_lds(false));
+}
+
+hipError_t junction_launch(const JuncParams &p, int num_cus, hipStream_t s)
+{
+    const bool ds = p.x != nullptr;
+    const int ngroups = (p.npix + 127) / 128;
+    const int per_cu = ds ? 1 : 2;  // 96 KB + vs 64 KB + of LDS
+    const int grid = ngroups < num_cus * per_cu ? ngroups : num_cus * per_cu;
+    if (ds) hipLaunchKernelGGL(junction_kernel<true>, dim3(grid), dim3(256), junc_lds(true), s, p);
+    else hipLaunchKernelGGL(junction_kernel<false>, dim3(grid), dim3(256), junc_lds(false), s, p);
+    return hipGetLastError();
+}

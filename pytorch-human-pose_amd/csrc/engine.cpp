@@ -233,18 +233,22 @@ struct Builder {
         tap("stem#0", X, 64);
 
         // stage 0: four Bottlenecks on one scale (hrnet.py:29-74), then the 256->C / 256->2C transition
-        const int t1 = T(64, 2), t2 = T(64, 2), Y = T(256, 2), D = T(256, 2);
+        const int t1 = T(64, 2), t2 = T(64, 2), Y = T(256, 2);
+        // conv3 (+ downsample) of unit u and conv1 of unit u+1 are both 1x1: one junction kernel makes y and the next t1 in a
+        // single pass over the 256-channel tensor (bottleneck_junction.hip)
+        auto unit = [&](int u) { return bb + ".stages.0.blocks.0.scales_blocks.0." + std::to_string(u); };
+        cb(unit(0), "conv1", "bn1", 64, 64, 1, 1, X, t1, 1);
         for (int u = 0; u < 4; ++u) {
-            const std::string up = bb + ".stages.0.blocks.0.scales_blocks.0." + std::to_string(u);
-            const int in = u == 0 ? X : Y, cin = u == 0 ? 64 : 256;
-            cb(up, "conv1", "bn1", cin, 64, 1, 1, in, t1, 1);
+            const std::string up = unit(u);
             cb(up, "conv2", "bn2", 64, 64, 3, 1, t1, t2, 1);
-            if (u == 0) {
-                cb(up, "downsample.0", "downsample.1", 64, 256, 1, 1, X, D, 0);
-                cb(up, "conv3", "bn3", 64, 256, 1, 1, t2, Y, 1, D);
-            } else {
-                cb(up, "conv3", "bn3", 64, 256, 1, 1, t2, Y, 1, Y);
-            }
+            Op o;
+            o.kind = OP_JUNC; o.lane = lane;
+            o.layer2 = u == 0 ? L(up + ".downsample.0", up + ".downsample.1", 64, 256, 1, 1) : -1;
+            o.layer = L(up + ".conv3", up + ".bn3", 64, 256, 1, 1);
+            o.layer3 = u < 3 ? L(unit(u + 1) + ".conv1", unit(u + 1) + ".bn1", 256, 64, 1, 1) : -1;
+            o.in = t2; o.in2 = u == 0 ? X : -1; o.res = u == 0 ? -1 : Y;
+            o.out = Y; o.out2 = u < 3 ? t1 : -1;
+            n.ops.push_back(o);
         }
         tap("stages.0.blocks.0#0", Y, 256);
         tap("stages.0.blocks.1#0", Y, 256);  // single-scale fusion = ReLU of a ReLU output
@@ -443,6 +447,7 @@ int hh_net::finalize()
         if (!p.loaded && !p.counter) { hh_set_error("hh_finalize: parameter never loaded: " + p.name); return 1; }
     HH_CHECK_HIP(conv_init());
     HH_CHECK_HIP(bb_fused_init());
+    HH_CHECK_HIP(junction_init());
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -651,6 +656,37 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         case OP_LINEAR:
             HH_CHECK_HIP(launch_linear(d_pool, d_fc_w, d_fc_b, o1, B, 2048, num_classes, s));
             break;
+        case OP_JUNC: {
+            const ConvLayer &l3 = layers[op.layer];
+            JuncParams p{};
+            p.t2 = tensors[op.in].ptr; p.t2_cs = tensors[op.in].C;
+            if (op.res >= 0) { p.res = tensors[op.res].ptr; p.res_cs = tensors[op.res].C; }
+            if (op.in2 >= 0) { p.x = tensors[op.in2].ptr; p.x_cs = tensors[op.in2].C; p.wd = layers[op.layer2].d_w; p.bd = layers[op.layer2].d_bias; }
+            p.w3 = l3.d_w; p.b3 = l3.d_bias;
+            if (op.layer3 >= 0) { p.w1 = layers[op.layer3].d_w; p.b1 = layers[op.layer3].d_bias; p.t1 = tensors[op.out2].ptr; p.t1_cs = tensors[op.out2].C; }
+            p.y = tensors[op.out].ptr; p.y_cs = tensors[op.out].C;
+            const TensorDesc &ti = tensors[op.in];
+            p.npix = B * (H >> ti.shift) * (W >> ti.shift);
+            ProfRecord *pr = nullptr;
+            if (prof_enabled) {
+                if (prof_used == prof.size()) {
+                    ProfRecord r{};
+                    HH_CHECK_HIP(hipEventCreate(&r.e0));
+                    HH_CHECK_HIP(hipEventCreate(&r.e1));
+                    prof.push_back(r);
+                }
+                pr = &prof[prof_used++];
+                pr->op = (int)(&op - ops.data());
+                pr->cfg = HH_CFG_JUNCTION;
+                pr->flops = 2.0 * p.npix * 64.0 * 256.0 * (1 + (op.in2 >= 0) + (op.layer3 >= 0));
+                pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
+                if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
+                HH_CHECK_HIP(hipEventRecord(pr->e0, s));
+            }
+            HH_CHECK_HIP(junction_launch(p, num_cus, s));
+            if (pr) HH_CHECK_HIP(hipEventRecord(pr->e1, s));
+            break;
+        }
         case OP_BB: {
             const ConvLayer &l1 = layers[op.layer], &l2 = layers[op.layer2];
             const TensorDesc &ti = tensors[op.in], &to = tensors[op.out];
@@ -786,6 +822,11 @@ double hh_net::flops(int B, int H, int W) const
         if (op.kind == OP_BB) {
             const TensorDesc &ti = tensors[op.in];
             macs += 2.0 * (double)(H >> ti.shift) * (W >> ti.shift) * 32.0 * 32.0 * 9.0;
+            continue;
+        }
+        if (op.kind == OP_JUNC) {
+            const TensorDesc &ti = tensors[op.in];
+            macs += (double)(H >> ti.shift) * (W >> ti.shift) * 64.0 * 256.0 * (1 + (op.in2 >= 0) + (op.layer3 >= 0));
             continue;
         }
         if (op.kind != OP_CONV) continue;

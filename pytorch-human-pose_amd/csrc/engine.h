@@ -45,11 +45,13 @@ struct TensorDesc {
     bool zero_init = false;
 };
 
-enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP };
+enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC };
 
 struct Op {
     OpKind kind = OP_CONV;
-    int layer = -1, layer2 = -1;  // layer2: second conv of a fused BasicBlock
+    int layer = -1, layer2 = -1;  // layer2: second conv of a fused BasicBlock / downsample conv of a junction (-1: none)
+    int layer3 = -1;              // OP_JUNC: first conv of the next Bottleneck (-1: none)
+    int in2 = -1, out2 = -1;      // OP_JUNC: downsample input x, and the t1 output
     int in = -1, in_coff = 0;
     int out = -1, out_coff = 0;
     int res = -1, res_coff = 0;

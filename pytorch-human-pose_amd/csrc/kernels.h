@@ -73,6 +73,22 @@ struct BBParams {
 hipError_t bb_fused_init();
 hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s);
 
+// Junction of two stage-0 Bottlenecks (bottleneck_junction.hip): y = relu(W3 t2 + shift (+ Wd x | + res)), t1 = relu(W1 y + shift1)
+struct JuncParams {
+    const bf16_raw *t2; int t2_cs;     // [npix, 64]  conv2 output of this unit
+    const bf16_raw *res; int res_cs;   // [npix, 256] previous y (units 1-3), or nullptr
+    const bf16_raw *x; int x_cs;       // [npix, 64]  unit-0 input of the downsample conv, or nullptr
+    const bf16_raw *w3, *wd, *w1;      // packed as the conv_mfma family packs 1x1 KC=32 NT=2 layers; wd / w1 may be nullptr
+    const float *b3, *bd, *b1;
+    bf16_raw *y; int y_cs;             // [npix, 256]
+    bf16_raw *t1; int t1_cs;           // [npix, 64] (only when w1)
+    int npix;
+    unsigned long long *clk;           // optional {min start, max end} device-clock probe
+};
+#define HH_CFG_JUNCTION 101  // pseudo instantiation index used by the profiler
+hipError_t junction_init();
+hipError_t junction_launch(const JuncParams &p, int num_cus, hipStream_t s);
+
 // fp32 NCHW [B,3,H,W] -> bf16 NHWC [B,H,W,16] (channels 3..15 zero)
 hipError_t launch_in_convert(const float *in, bf16_raw *out, int B, int H, int W, hipStream_t s);
 

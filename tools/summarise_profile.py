@@ -86,6 +86,9 @@ for n in set(fetch) | set(write):
     m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", n)
     if m:
         traffic["conv_mfma_kernel<KS=%s,S=%s,KC=%s,NT=%s,WC=%s,PT=%s,TW=%s>" % m.groups()] = round(total, -5)
+    elif "junction_kernel" in n:
+        key = "junction_kernel (stage-0 conv3 1x1 [+downsample] + residual + ReLU + next conv1 1x1 + ReLU)"
+        traffic[key] = max(traffic.get(key, 0.0), round(total, -5))
     elif n.startswith("bb_fused_kernel"):
         traffic["bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)"] = round(total, -5)
 DECODE = ("stage_average", "nms_tile_topk", "topk_merge", "match_kernel", "adjust_scores", "refine_", "tag_bounds")
