@@ -226,9 +226,13 @@ struct Builder {
         const int w[4] = {C, 2 * C, 4 * C, 8 * C};
         const std::string bb = "backbone";
         // stem (hrnet.py:354-358,378-384)
-        const int IN = T(16, 0), S1 = T(64, 1), X = T(64, 2);
-        { Op o; o.kind = OP_INCONVERT; o.out = IN; n.ops.push_back(o); }
-        conv(L(bb + ".conv1", bb + ".bn1", 3, 64, 3, 2), IN, S1, 1);
+        const int S1 = T(64, 1), X = T(64, 2);
+        {   // conv1 reads the fp32 NCHW images itself (stem_conv.hip): no layout pass, no padded input channels
+            Op o;
+            o.kind = OP_STEM; o.layer = L(bb + ".conv1", bb + ".bn1", 3, 64, 3, 2); o.out = S1;
+            n.layers[o.layer].stem = true;
+            n.ops.push_back(o);
+        }
         conv(L(bb + ".conv2", bb + ".bn2", 64, 64, 3, 2), S1, X, 1);
         tap("stem#0", X, 64);
 
@@ -457,6 +461,28 @@ int hh_net::finalize()
     }
     auto get = [&](const std::string &name) -> const std::vector<float> & { return params[param_index.at(name)].data; };
     for (auto &l : layers) {
+        if (l.stem) {  // [cout tile 2][k-step 2][half 2][32][8], tap = c*9 + ky*3 + kx, BN scale folded
+            const std::vector<float> &W = get(l.conv + ".weight");
+            std::vector<bf16_raw> packed(64 * 32, 0);
+            std::vector<float> shift(64);
+            for (int co = 0; co < 64; ++co) {
+                const float g = get(l.bn + ".weight")[co], bta = get(l.bn + ".bias")[co];
+                const float mu = get(l.bn + ".running_mean")[co], var = get(l.bn + ".running_var")[co];
+                const float sc = g / std::sqrt(var + 1e-5f);
+                shift[co] = bta - mu * sc;
+                for (int t = 0; t < 27; ++t) {
+                    const int kk = t / 16, hh = (t % 16) / 8, j = t % 8;
+                    packed[((((co / 32) * 2 + kk) * 2 + hh) * 32 + co % 32) * 8 + j] = f2bf(W[(size_t)co * 27 + t] * sc);
+                }
+            }
+            if (l.d_w) { hipFree(l.d_w); l.d_w = nullptr; }
+            if (l.d_bias) { hipFree(l.d_bias); l.d_bias = nullptr; }
+            HH_CHECK_HIP(hipMalloc((void **)&l.d_w, packed.size() * 2));
+            HH_CHECK_HIP(hipMalloc((void **)&l.d_bias, 64 * 4));
+            HH_CHECK_HIP(hipMemcpy(l.d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+            HH_CHECK_HIP(hipMemcpy(l.d_bias, shift.data(), 64 * 4, hipMemcpyHostToDevice));
+            continue;
+        }
         const int cin_pad0 = round_up(l.cin, 16), coutp = round_up(l.cout, 32);
         if (family_pick(l.ks, l.stride, cin_pad0, coutp, &l.KC, &l.NT)) {
             hh_set_error("no kernel family for conv " + l.conv);
@@ -622,6 +648,32 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         case OP_INCONVERT:
             HH_CHECK_HIP(launch_in_convert(images, tensors[op.out].ptr, B, H, W, s));
             break;
+        case OP_STEM: {
+            const ConvLayer &l = layers[op.layer];
+            StemParams p{};
+            p.images = images; p.w = l.d_w; p.bias = l.d_bias;
+            p.out = tensors[op.out].ptr; p.out_cs = tensors[op.out].C;
+            p.B = B; p.H = H; p.W = W;
+            ProfRecord *pr = nullptr;
+            if (prof_enabled) {
+                if (prof_used == prof.size()) {
+                    ProfRecord r{};
+                    HH_CHECK_HIP(hipEventCreate(&r.e0));
+                    HH_CHECK_HIP(hipEventCreate(&r.e1));
+                    prof.push_back(r);
+                }
+                pr = &prof[prof_used++];
+                pr->op = (int)(&op - ops.data());
+                pr->cfg = HH_CFG_STEM;
+                pr->flops = 2.0 * B * (H / 2) * (W / 2) * 27.0 * 64.0;
+                pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
+                if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
+                HH_CHECK_HIP(hipEventRecord(pr->e0, s));
+            }
+            HH_CHECK_HIP(stem_conv_launch(p, s));
+            if (pr) HH_CHECK_HIP(hipEventRecord(pr->e1, s));
+            break;
+        }
         case OP_UPADD: {
             UpAddParams p{};
             const TensorDesc &b = tensors[op.in], &o = tensors[op.out];
@@ -824,6 +876,7 @@ double hh_net::flops(int B, int H, int W) const
             macs += 2.0 * (double)(H >> ti.shift) * (W >> ti.shift) * 32.0 * 32.0 * 9.0;
             continue;
         }
+        if (op.kind == OP_STEM) { macs += (double)(H / 2) * (W / 2) * 27.0 * 64.0; continue; }
         if (op.kind == OP_JUNC) {
             const TensorDesc &ti = tensors[op.in];
             macs += (double)(H >> ti.shift) * (W >> ti.shift) * 64.0 * 256.0 * (1 + (op.in2 >= 0) + (op.layer3 >= 0));

@@ -32,6 +32,7 @@ struct ConvLayer {
     std::string conv, bn, bias;  // state-dict prefixes ("" = absent)
     int cin = 0, cout = 0, ks = 1, stride = 1;
     bool transposed = false;
+    bool stem = false;  // first conv of the net: packed for stem_conv.hip (K = 27 taps padded to 32)
     int py = 0, px = 0;  // phase of the transposed conv this entry implements
     // chosen at finalize
     int KC = 0, NT = 0, cin_pad = 0, ncg = 0;
@@ -45,7 +46,7 @@ struct TensorDesc {
     bool zero_init = false;
 };
 
-enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC };
+enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC, OP_STEM };
 
 struct Op {
     OpKind kind = OP_CONV;

@@ -89,6 +89,18 @@ struct JuncParams {
 hipError_t junction_init();
 hipError_t junction_launch(const JuncParams &p, int num_cus, hipStream_t s);
 
+// First stem conv (stem_conv.hip): fp32 NCHW images -> conv3x3 s2 p1 (3->64) + BN + ReLU -> bf16 NHWC [B,H/2,W/2,out_cs]
+struct StemParams {
+    const float *images;      // [B,3,H,W]
+    const bf16_raw *w;        // [cout tile 2][k-step 2][half 2][32 couts][8 taps] bf16, tap = c*9 + ky*3 + kx, BN scale folded, taps 27..31 zero
+    const float *bias;        // [64]
+    bf16_raw *out; int out_cs;
+    int B, H, W;              // H, W even
+    unsigned long long *clk;  // optional device-clock probe
+};
+#define HH_CFG_STEM 102  // pseudo instantiation index used by the profiler
+hipError_t stem_conv_launch(const StemParams &p, hipStream_t s);
+
 // fp32 NCHW [B,3,H,W] -> bf16 NHWC [B,H,W,16] (channels 3..15 zero)
 hipError_t launch_in_convert(const float *in, bf16_raw *out, int B, int H, int W, hipStream_t s);
 
