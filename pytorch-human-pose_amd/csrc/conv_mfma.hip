@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 
     const int tid = threadIdx.x;
 #ifndef HH_NO_CLK
-    if (p.clk && tid == 0) atomicMin(p.clk, wall_clock64());
+    // (grids reach 16384 workgroups: only the first / last 256 dispatched stamp, or the same-address atomics would show up
+    // in the very duration they measure)
+    if (p.clk && tid == 0 && blockIdx.x < 256) atomicMin(p.clk, wall_clock64());
 #endif
     const int wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
         }
     }
 #ifndef HH_NO_CLK
-    if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
+    if (p.clk && tid == 0 && blockIdx.x + 256 >= gridDim.x) atomicMax(p.clk + 1, wall_clock64());
 #endif
 }
 

@@ -605,7 +605,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         *e = lane_events[lane_events_used++];
         return 0;
     };
-    if (prof_enabled) {  // device-clock slots: starts = ~0, ends = 0
+    if (prof_enabled && prof_used == 0) {  // first forward since hh_profile_enable: device-clock slots start as {~0, 0}
         if (!d_clk) {
             HH_CHECK_HIP(hipMalloc((void **)&d_clk, HH_PROF_SLOTS * 16));
             int dev = 0, khz = 0;

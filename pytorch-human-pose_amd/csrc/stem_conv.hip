@@ -33,7 +33,9 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p)
     __shared__ unsigned short patch[NVAL + 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
 #ifndef HH_NO_CLK
-    if (p.clk && tid == 0) atomicMin(p.clk, wall_clock64());
+    // 8192 workgroups hammering one address would dominate this short kernel: only the first and the last 256 dispatched
+    // workgroups stamp (dispatch order follows blockIdx closely enough for a start/end probe)
+    if (p.clk && tid == 0 && blockIdx.x < 256) atomicMin(p.clk, wall_clock64());
 #endif
     const int Ho = p.H >> 1, Wo = p.W >> 1;
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
@@ -52,14 +54,25 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p)
 
     // ---- patch: fp32 NCHW -> bf16 LDS [c][row][col], zero outside the image (conv padding)
     const float *img = p.images + (size_t)b * 3 * p.H * p.W;
-    for (int i = tid; i < NVAL; i += 256) {
+    constexpr int NLD = (NVAL + 255) / 256;  // 13 loads per thread, all issued before the first one is touched
+    float v[NLD];
+    unsigned okmask = 0;  // the loads are not touched (nor predicated) here: zero padding is applied when they go to LDS
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int i = tid + 256 * it;
         const int c = i / PLANE, rem = i % PLANE, py = rem / PW, px = rem % PW;
         const int iy = iy0 + py, ix = ix0 + px;
-        const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-        const float v = ok ? img[((size_t)c * p.H + iy) * p.W + ix] : 0.f;
-        patch[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        const bool ok = (i < NVAL) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        const int o = ok ? (c * p.H + iy) * p.W + ix : 0;
+        v[it] = img[o];
+        okmask |= ok ? (1u << it) : 0u;
     }
-    if (tid == 0) patch[NVAL] = 0;
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int i = tid + 256 * it;
+        const float x = (okmask >> it) & 1u ? v[it] : 0.f;
+        patch[i < NVAL ? i : NVAL] = __builtin_bit_cast(unsigned short, (__bf16)x);  // idle slots of the last round hit the zero slot
+    }
     // tap t = kk*16 + 8h + j  ->  (c, ky, kx) = (t / 9, (t % 9) / 3, t % 3); taps >= 27 read the zero slot
     int off[2][8];
 #pragma unroll
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p)
         }
     }
 #ifndef HH_NO_CLK
-    if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
+    if (p.clk && tid == 0 && blockIdx.x + 256 >= gridDim.x) atomicMax(p.clk + 1, wall_clock64());
 #endif
 }
 
