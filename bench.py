@@ -137,12 +137,12 @@ def main():
     side2 = torch.cuda.Stream(dev)  # decode stream
     outs = (torch.empty(B, 2 * K, H // 4, W // 4, device=dev), torch.empty(B, K, H // 2, W // 2, device=dev))
 
-    def step():
+    def step(isolate=False):
         # The two halves of a step have no data dependency (forward consumes images, decode consumes maps -- in
         # serving, decode of batch i runs beside the forward of batch i+1), so they are issued on two streams
         # unless --sequential is given.
         out = net.forward_raw(images, outs)
-        if args.sequential:
+        if args.sequential or isolate:
             dec = parser.decode_batch_device(hm_q, hm_h, [tags], adjust=True, refine=True)
         else:
             with torch.cuda.stream(side2):
@@ -163,7 +163,12 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             if profile and i == args.steps - 1:
-                lib.hh_profile_enable(net._h, 1)  # last timed step: eager launches + per-conv HIP events
+                # last timed step: conv launches one at a time with the device-clock probe + HIP events, and the decode
+                # behind them on the same stream (a decode kernel running beside a probed conv would inflate its duration)
+                side2.synchronize()
+                lib.hh_profile_enable(net._h, 1)
+                out, dec = step(isolate=True)
+                continue
             out, dec = step()
         torch.cuda.synchronize()
         if dist is not None:
@@ -218,7 +223,7 @@ def main():
                 "forward_tflops": round(net.forward_flops(B, H, W) / parts[0] / 1e12, 1),
                 "streams": "forward and decode issued back to back on one stream" if args.sequential else
                            "forward (+3 internal branch lanes) and decode on two streams",
-                "timed_region": "eager multi-lane launches; last step single-lane with per-conv HIP events" if profile
+                "timed_region": "eager multi-lane launches, decode on a second stream; last step: kernels one at a time on one stream with the per-launch probe" if profile
                                 else "eager multi-lane launches",
             },
         }
