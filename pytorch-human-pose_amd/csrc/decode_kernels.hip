@@ -107,9 +107,6 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     __shared__ float rm[HS][TS + 1];
     __shared__ float patch[PR][PR + 1];  // half-res source rows/cols of this tile (mode 0)
     __shared__ u64 wbest[2][4];
-    __shared__ short li0[2][HS], li1[2][HS];  // [0] rows, [1] columns: patch-relative source indices
-    __shared__ float lw0[2][HS], lw1[2][HS];
-    __shared__ bool lin[2][HS];              // row / column inside the image
     const int tile = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
     const int ty = tile / tiles_x, tx = tile % tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
@@ -125,30 +122,20 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             const int r = i / PR, c = i % PR;
             patch[r][c] = img[(size_t)min(py0 + r, hh - 1) * wh + min(px0 + c, wh - 1)];
         }
-        // bilinear weights of the tile's 68 rows and 68 columns, once (they were recomputed per pixel)
-        if (tid < 2 * HS) {
-            const bool isx = tid >= HS;
-            const int l = isx ? tid - HS : tid, P = (isx ? x0 : y0) - 2 + l, lim = isx ? src.W : src.H;
-            const Lin a = src_index(isx ? wh : hh, isx ? src.scale_w2 : src.scale_h2, min(max(P, 0), lim - 1));
-            li0[isx][l] = (short)(a.i0 - (isx ? px0 : py0)); li1[isx][l] = (short)(a.i1 - (isx ? px0 : py0));
-            lw0[isx][l] = a.w0; lw1[isx][l] = a.w1;
-            lin[isx][l] = (P >= 0 && P < lim);
-        }
-        __syncthreads();
-        // separable: the horizontal interpolation of a half-res row serves both full-res rows that use it
-        // (same expressions, same order as bilerp(): bit-identical, 3.8x fewer of them)
-        float (*th)[HS + 1] = reinterpret_cast<float (*)[HS + 1]>(&rm[0][0]);  // [PR][HS+1] fits inside rm
-        for (int i = tid; i < PR * HS; i += 256) {
-            const int pr = i / HS, lx = i % HS;
-            th[pr][lx] = __builtin_fmaf(patch[pr][li0[1][lx]], lw0[1][lx], patch[pr][li1[1][lx]] * lw1[1][lx]);
-        }
         __syncthreads();
         for (int i = tid; i < HS * HS; i += 256) {
             const int ly = i / HS, lx = i % HS;
-            const float val = __builtin_fmaf(th[li0[0][ly]][lx], lw0[0][ly], th[li1[0][ly]][lx] * lw1[0][ly]);
-            v[ly][lx] = (lin[0][ly] && lin[1][lx]) ? val : -INFINITY;
+            const int Y = y0 - 2 + ly, X = x0 - 2 + lx;
+            float val = -INFINITY;
+            if (Y >= 0 && Y < src.H && X >= 0 && X < src.W) {
+                const Lin a = src_index(hh, src.scale_h2, Y), c = src_index(wh, src.scale_w2, X);
+                const float *r0 = patch[a.i0 - py0], *r1 = patch[a.i1 - py0];
+                const float t0 = __builtin_fmaf(r0[c.i0 - px0], c.w0, r0[c.i1 - px0] * c.w1);
+                const float t1 = __builtin_fmaf(r1[c.i0 - px0], c.w0, r1[c.i1 - px0] * c.w1);
+                val = __builtin_fmaf(t0, a.w0, t1 * a.w1);
+            }
+            v[ly][lx] = val;
         }
-        __syncthreads();  // th (= rm) is rewritten by the row-max pass below
     } else {
         for (int i = tid; i < HS * HS; i += 256) {
             const int ly = i / HS, lx = i % HS;

@@ -1,0 +1,16 @@
+"""Time hh_decode alone on the bench's constructed maps (GPU box): python tools/decode_time.py"""
+import importlib, os, sys, time
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+pkg = importlib.import_module("pytorch-human-pose_amd")
+K, H, W, B = 17, 512, 512, 32
+uniq = [pkg.synth.synth_decode_maps(K, H // 4, W // 4, 10, seed=1000 + i)[:3] for i in range(8)]
+hm_q = torch.from_numpy(np.stack([uniq[i % 8][0] for i in range(B)])).cuda()
+hm_h = torch.from_numpy(np.stack([uniq[i % 8][1] for i in range(B)])).cuda()
+tags = torch.from_numpy(np.stack([uniq[i % 8][2][0] for i in range(B)])).cuda()
+parser = pkg.MPPEHeatmapParser(K, 30, 0.05, 0.5)
+for _ in range(3): parser.decode_batch_device(hm_q, hm_h, [tags])
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(20): parser.decode_batch_device(hm_q, hm_h, [tags])
+torch.cuda.synchronize(); print(f"decode {(time.perf_counter() - t) / 20 * 1e3:.3f} ms / batch of {B}")
