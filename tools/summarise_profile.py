@@ -20,7 +20,7 @@ prof = os.path.join(root, "profiles")
 
 
 def one(pattern):
-    hits = sorted(glob.glob(os.path.join(out, pattern), recursive=True), key=os.path.getsize)
+    hits = sorted(glob.glob(os.path.join(out, pattern), recursive=True), key=os.path.getmtime)  # newest run wins
     if not hits:
         sys.exit(f"missing {pattern}")
     return hits[-1]
@@ -73,6 +73,31 @@ for r in stats:
     lines.append(f"| `{short(n)}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(sr['AverageNs']) / 1e3 if sr else float('nan'):.1f} | "
                  f"{float(sr['Percentage']) if sr else float('nan'):.2f} | "
                  f"{2 * fetch.get(n, 0.0) / 1e6:.1f} | {write.get(n, 0.0) / 1e6:.1f} |")
+# SQ counter pass (tools/pmc_pass.sh): MFMA pipe occupancy and where the waves' cycles go
+sq_files = sorted(glob.glob(os.path.join(out, f"{tag}_sq/**/*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+if sq_files:
+    acc, cnt = defaultdict(lambda: defaultdict(float)), defaultdict(int)
+    with open(sq_files[-1]) as f:
+        for r in csv.DictReader(f):
+            acc[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[r["Kernel_Name"]] += r["Counter_Name"] == "SQ_WAVE_CYCLES"
+    lines += ["", "## SQ counters (`bash tools/pmc_pass.sh " + tag + "`: serial bench, `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES "
+              "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE`)", "",
+              "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (serial duration x 2.4 GHz x 1024 SIMDs); a 32x32x16 bf16 MFMA holds the pipe "
+              "32 cycles, so busy cycles = 32 x MFMAs issued (halo recompute and identity-residual MFMAs included).  WAIT_ANY = parked on "
+              "s_waitcnt/barrier, WAIT_INST = issue stall (mostly the matrix pipe held by the other wave of the SIMD), ACTIVE = issuing.", "",
+              "| kernel | MFMA busy cycles / launch | MFMA util (at 2.4 GHz) | wave cycles: wait_any / wait_inst / active % | LDS bank-conflict cycles / launch |",
+              "|---|---|---|---|---|"]
+    rows = []
+    for n, v in acc.items():
+        k = cnt[n] or 1
+        if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and n in serial:
+            dur = float(serial[n]["AverageNs"]) * 1e-9
+            wc = v["SQ_WAVE_CYCLES"] or 1.0
+            rows.append((float(serial[n]["Percentage"]), f"| `{short(n)}` | {v['SQ_VALU_MFMA_BUSY_CYCLES'] / k:.3g} | "
+                         f"{v['SQ_VALU_MFMA_BUSY_CYCLES'] / k / (dur * 2.4e9 * 1024):.3f} | {100 * v['SQ_WAIT_ANY'] / wc:.0f} / "
+                         f"{100 * v['SQ_WAIT_INST_ANY'] / wc:.0f} / {100 * v['SQ_ACTIVE_INST_ANY'] / wc:.0f} | {v['SQ_LDS_BANK_CONFLICT'] / k:.3g} |"))
+    lines += [r for _, r in sorted(rows, reverse=True)[:12]]
 for which in ("stats", "serial"):
     for ln in open(os.path.join(out, f"{tag}_{which}.log"), errors="replace"):
         if ln.startswith('{"metric"'):
