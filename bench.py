@@ -10,9 +10,12 @@ Multi-GPU: the path shards by image (no collective on the data path); every rank
 per-GPU batch (weak scaling), timing is barrier + synchronize on both sides, max over ranks.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live inside the timed region: steps 1..K-1 run as they would in
-production (eager launches, branch lanes on internal streams), the K-th (last) timed step runs single-lane with HIP
-events bracketing every convolution launch on the launch stream (hh_profile_*); the dominant kernel instantiation is the one with the largest
-summed time in that step.  `cpu_baseline` times the CPU oracle (oracle/) on a bounded sample on rank 0.
+production (eager launches, branch lanes on internal streams, decode on a second stream); in the K-th (last) timed step
+the kernels run one at a time on one stream and every convolution launch is timed twice -- by the kernel itself on the
+device wall clock (first workgroup start to last workgroup end: the figure rocprofv3's kernel trace reports) and by a
+HIP-event bracket on the launch stream (hh_profile_*).  The dominant kernel instantiation is the one with the largest
+summed time in that step.  `decode_roofline` = compulsory decode bytes over the time of hh_decode alone, against HBM
+peak.  `cpu_baseline` times the CPU oracle (oracle/) on a bounded sample, on rank 0 at N=1 only.
 """
 import argparse
 import ctypes as C
@@ -268,7 +271,7 @@ def main():
             "frac": round(dec_bytes / parts[1] / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic_for("hh_decode (all kernels of one call)"),
             "algorithmic_bytes_per_call": dec_bytes, "ms_per_call": round(parts[1] * 1e3, 3),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: the other ranks would idle at the final barrier
             line["cpu_baseline"] = cpu_baseline(pkg, sd, uniq)
         print(json.dumps(line), flush=True)
     if dist is not None:

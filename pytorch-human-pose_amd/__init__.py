@@ -2,6 +2,7 @@
 `src.keypoints` model/inference API of thawro/pytorch-human-pose).  See DESIGN.md."""
 from . import _lib, synth
 from .classification.architectures import ClassificationHRNet
-from .keypoints import HigherHRNet, InferenceKeypointsModel, InferenceKeypointsResult, MPPEHeatmapParser
+from . import keypoints
+from .keypoints import AEKeypointsLoss, HigherHRNet, InferenceKeypointsModel, InferenceKeypointsResult, MPPEHeatmapParser
 
 __all__ = ["ClassificationHRNet", "HigherHRNet", "MPPEHeatmapParser", "InferenceKeypointsModel", "InferenceKeypointsResult", "synth", "_lib"]

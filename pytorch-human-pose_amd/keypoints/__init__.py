@@ -4,3 +4,5 @@ from .model import InferenceKeypointsModel
 from .results import InferenceKeypointsResult
 
 __all__ = ["HigherHRNet", "MPPEHeatmapParser", "InferenceKeypointsModel", "InferenceKeypointsResult"]
+from .loss import AEGroupingLoss, AEKeypointsLoss, HeatmapsLoss
+from . import evaluation, targets
