@@ -186,26 +186,42 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             cellmax[(((size_t)b * src.K + k) * (src.H >> 2) + (Y >> 2)) * (src.W >> 2) + (X >> 2)] = m;
         }
     }
-    for (int i = tid; i < HS * TS; i += 256) {
-        const int ly = i / TS, lx = i % TS;
-        float m = v[ly][lx];
+    // separable 5x5 maximum with sliding windows in registers: 16 outputs from 20 inputs (pair maxima, then pairs of
+    // pairs, then the fifth element) instead of 5 LDS reads + 4 max per output
+    auto slide16 = [](const float (&in)[20], float (&out)[16]) {
+        float p2[19], p4[17];
 #pragma unroll
-        for (int d = 1; d < 5; ++d) m = fmaxf(m, v[ly][lx + d]);
-        rm[ly][lx] = m;
+        for (int i = 0; i < 19; ++i) p2[i] = fmaxf(in[i], in[i + 1]);
+#pragma unroll
+        for (int i = 0; i < 17; ++i) p4[i] = fmaxf(p2[i], p2[i + 2]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[i] = fmaxf(p4[i], in[i + 4]);
+    };
+    for (int it = tid; it < HS * (TS / 16); it += 256) {  // rows: 68 x 4 strips of 16 outputs
+        const int ly = it / (TS / 16), lx0 = (it % (TS / 16)) * 16;
+        float in[20], out[16];
+#pragma unroll
+        for (int i = 0; i < 20; ++i) in[i] = v[ly][lx0 + i];
+        slide16(in, out);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rm[ly][lx0 + i] = out[i];
     }
     __syncthreads();
     u64 keys[16];
     float vals[16];
+    const int mpx = tid % TS, mpy0 = (tid / TS) * 16;  // this thread's pixels: column mpx, rows mpy0 .. mpy0+15
+    {
+        float in[20], out[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int p = tid + 256 * j, py = p / TS, px = p % TS;
-        float m = rm[py][px];
+        for (int i = 0; i < 20; ++i) in[i] = rm[mpy0 + i][mpx];
+        slide16(in, out);
 #pragma unroll
-        for (int d = 1; d < 5; ++d) m = fmaxf(m, rm[py + d][px]);
-        const float c = v[py + 2][px + 2];
-        const int Y = y0 + py, X = x0 + px;
-        vals[j] = c * ((m == c) ? 1.0f : 0.0f);
-        keys[j] = (Y < src.H && X < src.W) ? make_key(vals[j], (unsigned)(Y * src.W + X)) : 0ull;
+        for (int j = 0; j < 16; ++j) {
+            const float c = v[mpy0 + j + 2][mpx + 2];
+            const int Y = y0 + mpy0 + j, X = x0 + mpx;
+            vals[j] = c * ((out[j] == c) ? 1.0f : 0.0f);
+            keys[j] = (Y < src.H && X < src.W) ? make_key(vals[j], (unsigned)(Y * src.W + X)) : 0ull;
+        }
     }
     const size_t obase = ((((size_t)b * src.K + k) * gridDim.x) + tile) * M;
     // The tile's ordering is: positive peaks (value desc), then zero-valued pixels (index asc), then negative
@@ -217,10 +233,7 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     __syncthreads();           // everyone is done reading rm
     if (tid == 0) { ccount = 0; nfilled = 0; }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int p = tid + 256 * j;
-        nv[p / TS][p % TS] = keys[j] ? vals[j] : __builtin_nanf("");  // NaN = outside the image
-    }
+    for (int j = 0; j < 16; ++j) nv[mpy0 + j][mpx] = keys[j] ? vals[j] : __builtin_nanf("");  // NaN = outside the image
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; ++j)
