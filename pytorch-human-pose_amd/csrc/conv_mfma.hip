@@ -76,12 +76,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     char *lds_w = smem + PATCH_BYTES;
 
     int bid = blockIdx.x;
+    // Fused transposed-conv phases: blocks {t, t+8, t+16, t+24} of every group of 32 are the four phases of one tile.
+    // Workgroups are dealt to the 8 XCDs round-robin, so the four land on the same XCD and the tile's input patch comes
+    // from HBM once and from that XCD's L2 three times.
+    int ph = 0;
+    if (p.nphase > 1) {
+        ph = (bid >> 3) & 3;
+        bid = (bid & 7) | ((bid >> 5) << 3);
+        if (bid >= p.B * p.tiles_y * p.tiles_x * p.ncg) return;  // padding of the last group (before any barrier)
+    }
+    const int pad_y = p.nphase > 1 ? ((ph >> 1) ? 0 : 1) : p.pad_y, pad_x = p.nphase > 1 ? ((ph & 1) ? 0 : 1) : p.pad_x;
+    const int ooy = p.nphase > 1 ? (ph >> 1) : p.ooy, oox = p.nphase > 1 ? (ph & 1) : p.oox;
     const int cg = bid % p.ncg; bid /= p.ncg;
     const int tx = bid % p.tiles_x; bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
     const int b = bid / p.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * S - p.pad_y, ix0 = ox0 * S - p.pad_x;
+    const int iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
 
     const int tid = threadIdx.x;
 #ifndef HH_NO_CLK
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     const int dy = r / TW, dx = r % TW;
 
     const int nchunks = p.cin / KC;
-    const u32x4 *w_cg = reinterpret_cast<const u32x4 *>(p.w) + (size_t)cg * nchunks * W_UNITS;
+    const u32x4 *w_cg = reinterpret_cast<const u32x4 *>(p.w + (size_t)ph * p.phase_stride) + (size_t)cg * nchunks * W_UNITS;
 
     // ---- chunk-invariant geometry of this thread's staging units: source pointer of chunk 0 and an
     //      "inside the image" bit per unit (outside = conv zero padding, applied when the unit is written to LDS)
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
             for (int pt = 0; pt < PT; ++pt) {
                 const int oy = oy0 + (wp * PT + pt) * RPT + dy, ox = ox0 + dx;
                 const bool valid = oy < p.Ho && ox < p.Wo;
-                const size_t pix = valid ? ((size_t)b * p.Hob + (oy * p.osy + p.ooy)) * p.Wob + (ox * p.osx + p.oox) : 0;
+                const size_t pix = valid ? ((size_t)b * p.Hob + (oy * p.osy + ooy)) * p.Wob + (ox * p.osx + oox) : 0;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     for (int pt = 0; pt < PT; ++pt) {
         const int oy = oy0 + (wp * PT + pt) * RPT + dy, ox = ox0 + dx;
         const bool valid = oy < p.Ho && ox < p.Wo;
-        const int Y = oy * p.osy + p.ooy, X = ox * p.osx + p.oox;
+        const int Y = oy * p.osy + ooy, X = ox * p.osx + oox;
         const size_t pix = ((size_t)b * p.Hob + Y) * p.Wob + X;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -383,7 +394,8 @@ hipError_t conv_init()
 hipError_t conv_launch(int cfg_index, const ConvParams &p, hipStream_t stream)
 {
     const ConvConfig &c = g_configs[cfg_index];
-    const unsigned grid = (unsigned)p.B * p.tiles_y * p.tiles_x * p.ncg;
+    unsigned grid = (unsigned)p.B * p.tiles_y * p.tiles_x * p.ncg;
+    if (p.nphase > 1) grid = (grid + 7) / 8 * 32;  // groups of 8 tiles x 4 phases
     hipLaunchKernelGGL(g_fns[cfg_index], dim3(grid), dim3(256), c.lds_bytes(), stream, p);
     return hipGetLastError();
 }

@@ -377,13 +377,12 @@ struct Builder {
         // DeconvHeatmapsHead (higher_hrnet.py:7-44): ConvTranspose2d(k4,s2,p1) = 4 phase-wise 2x2 convs
         const std::string dp = "deconv_layers.0";
         const int DF = T(C, 1), DM = T(C, 1);
-        for (int py = 0; py < 2; ++py)
-            for (int px = 0; px < 2; ++px) {
-                const int l = L(dp + ".deconv.0", dp + ".deconv.1", C + 2 * K, C, 2, 1);
-                n.layers[l].transposed = true; n.layers[l].py = py; n.layers[l].px = px;
-                Op &o = conv(l, CAT, DF, 1);
-                o.scatter = 1;
-            }
+        {   // one launch: the four phase weight sets are packed back to back (py = -1 marks "all phases")
+            const int l = L(dp + ".deconv.0", dp + ".deconv.1", C + 2 * K, C, 2, 1);
+            n.layers[l].transposed = true; n.layers[l].py = -1; n.layers[l].px = -1;
+            Op &o = conv(l, CAT, DF, 1);
+            o.scatter = 1;
+        }
         basic_blocks(dp + ".resid_blocks", C, DF, DM);
         tap("deconv#0", DF, C);
         {
@@ -508,7 +507,15 @@ int hh_net::finalize()
             }
         }
         std::vector<bf16_raw> packed;
-        hh_pack_weights(W.data(), scale.data(), l.ks, l.cin, l.cout, l.KC, COUT_T, l.transposed, l.py, l.px, packed);
+        if (l.transposed && l.py < 0) {
+            for (int ph = 0; ph < 4; ++ph) {
+                std::vector<bf16_raw> one;
+                hh_pack_weights(W.data(), scale.data(), l.ks, l.cin, l.cout, l.KC, COUT_T, true, ph >> 1, ph & 1, one);
+                l.phase_stride = one.size();
+                packed.insert(packed.end(), one.begin(), one.end());
+            }
+        } else
+            hh_pack_weights(W.data(), scale.data(), l.ks, l.cin, l.cout, l.KC, COUT_T, l.transposed, l.py, l.px, packed);
         if (l.d_w) { hipFree(l.d_w); l.d_w = nullptr; }
         if (l.d_bias) { hipFree(l.d_bias); l.d_bias = nullptr; }
         HH_CHECK_HIP(hipMalloc((void **)&l.d_w, packed.size() * 2));
@@ -780,6 +787,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             if (l.transposed) {
                 p.osy = p.osx = 2; p.ooy = l.py; p.oox = l.px;
                 p.pad_y = l.py == 0 ? 1 : 0; p.pad_x = l.px == 0 ? 1 : 0;
+                if (l.py < 0) { p.nphase = 4; p.phase_stride = l.phase_stride; }
             }
             p.Hob = p.Ho * p.osy; p.Wob = p.Wo * p.osx;
             if (op.out >= 0) {
@@ -814,7 +822,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->cfg = cfg;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
                 if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
-                pr->flops = 2.0 * B * p.Ho * p.Wo * (double)l.cin * l.cout * l.ks * l.ks;
+                pr->flops = 2.0 * B * p.Ho * p.Wo * (double)l.cin * l.cout * l.ks * l.ks * (p.nphase > 1 ? 4 : 1);
                 HH_CHECK_HIP(hipEventRecord(pr->e0, s));
             }
             HH_CHECK_HIP(conv_launch(cfg, p, s));
@@ -888,7 +896,7 @@ double hh_net::flops(int B, int H, int W) const
         const double hin = H >> ti.shift, win = W >> ti.shift;
         const double ho = l.stride == 2 ? hin / 2 : hin, wo = l.stride == 2 ? win / 2 : win;
         // a transposed-conv phase: every input pixel meets 4 of the 16 taps per phase (16 over the 4 phases)
-        macs += ho * wo * (double)l.cin * l.cout * l.ks * l.ks;
+        macs += ho * wo * (double)l.cin * l.cout * l.ks * l.ks * ((l.transposed && l.py < 0) ? 4 : 1);
     }
     if (kind == 1) macs += 2048.0 * num_classes;
     return 2.0 * macs * B;

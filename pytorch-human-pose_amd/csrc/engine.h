@@ -33,7 +33,8 @@ struct ConvLayer {
     int cin = 0, cout = 0, ks = 1, stride = 1;
     bool transposed = false;
     bool stem = false;  // first conv of the net: packed for stem_conv.hip (K = 27 taps padded to 32)
-    int py = 0, px = 0;  // phase of the transposed conv this entry implements
+    int py = 0, px = 0;  // phase of the transposed conv this entry implements (-1: all four, packed back to back)
+    size_t phase_stride = 0;
     // chosen at finalize
     int KC = 0, NT = 0, cin_pad = 0, ncg = 0;
     bf16_raw *d_w = nullptr;

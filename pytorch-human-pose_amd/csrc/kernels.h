@@ -25,6 +25,8 @@ struct ConvParams {
     int relu;
     int pad_y, pad_x;     // top/left zero padding
     int B, tiles_x, tiles_y, ncg;
+    int nphase;           // 4: the four 2x2 phases of a 4x4 stride-2 transposed conv in ONE launch (pad / output offset follow the
+    size_t phase_stride;  //    phase index, weights of phase f start at w + f * phase_stride elements); 0 or 1: plain conv
     unsigned long long *stamps;  // diagnostic build (-DHH_STAMP) only
     unsigned long long *clk;     // optional {min start, max end} of the launch in wall_clock64() ticks (profiling probe)
     const bf16_raw *zero;        // >= 16 zero bytes (16-B aligned): DMA source of out-of-image pixels (conv3x3_dma.hip)
