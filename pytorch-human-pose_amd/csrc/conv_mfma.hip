@@ -76,18 +76,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     char *lds_w = smem + PATCH_BYTES;
 
     int bid = blockIdx.x;
-    // Fused transposed-conv phases: blocks {t, t+8, t+16, t+24} of every group of 32 are the four phases of one tile.
-    // Workgroups are dealt to the 8 XCDs round-robin, so the four land on the same XCD and the tile's input patch comes
-    // from HBM once and from that XCD's L2 three times.
-    int ph = 0;
-    if (p.nphase > 1) {
-        ph = (bid >> 3) & 3;
-        bid = (bid & 7) | ((bid >> 5) << 3);
-        if (bid >= p.B * p.tiles_y * p.tiles_x * p.ncg) return;  // padding of the last group (before any barrier)
+    // XCD-aware block order.  Workgroups are dealt to the 8 XCDs round-robin, and the SF = ncg * nphase workgroups that
+    // read the same input patch (the cout groups of a tile; the four phases of a fused transposed conv) should share an
+    // XCD so that the patch comes from HBM / MALL once and from that XCD's L2 afterwards: blocks {t, t+8, ..., t+8(SF-1)}
+    // of every group of 8*SF are the SF variants of one tile.
+    const int nph = p.nphase > 1 ? p.nphase : 1, SF = p.ncg * nph;
+    int sub = 0;
+    if (SF > 1) {
+        sub = (bid >> 3) % SF;
+        bid = (bid & 7) | ((bid / (8 * SF)) << 3);
+        if (bid >= p.B * p.tiles_y * p.tiles_x) return;  // padding of the last group (before any barrier)
     }
-    const int pad_y = p.nphase > 1 ? ((ph >> 1) ? 0 : 1) : p.pad_y, pad_x = p.nphase > 1 ? ((ph & 1) ? 0 : 1) : p.pad_x;
-    const int ooy = p.nphase > 1 ? (ph >> 1) : p.ooy, oox = p.nphase > 1 ? (ph & 1) : p.oox;
-    const int cg = bid % p.ncg; bid /= p.ncg;
+    const int cg = sub % p.ncg, ph = sub / p.ncg;
+    const int pad_y = nph > 1 ? ((ph >> 1) ? 0 : 1) : p.pad_y, pad_x = nph > 1 ? ((ph & 1) ? 0 : 1) : p.pad_x;
+    const int ooy = nph > 1 ? (ph >> 1) : p.ooy, oox = nph > 1 ? (ph & 1) : p.oox;
     const int tx = bid % p.tiles_x; bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
     const int b = bid / p.tiles_y;
@@ -394,8 +396,8 @@ hipError_t conv_init()
 hipError_t conv_launch(int cfg_index, const ConvParams &p, hipStream_t stream)
 {
     const ConvConfig &c = g_configs[cfg_index];
-    unsigned grid = (unsigned)p.B * p.tiles_y * p.tiles_x * p.ncg;
-    if (p.nphase > 1) grid = (grid + 7) / 8 * 32;  // groups of 8 tiles x 4 phases
+    const unsigned tiles = (unsigned)p.B * p.tiles_y * p.tiles_x, sf = (unsigned)p.ncg * (p.nphase > 1 ? p.nphase : 1);
+    const unsigned grid = sf > 1 ? (tiles + 7) / 8 * 8 * sf : tiles;  // groups of 8 tiles x sf variants (see the kernel)
     hipLaunchKernelGGL(g_fns[cfg_index], dim3(grid), dim3(256), c.lds_bytes(), stream, p);
     return hipGetLastError();
 }
