@@ -5,4 +5,4 @@ from .results import InferenceKeypointsResult
 
 __all__ = ["HigherHRNet", "MPPEHeatmapParser", "InferenceKeypointsModel", "InferenceKeypointsResult"]
 from .loss import AEGroupingLoss, AEKeypointsLoss, HeatmapsLoss
-from . import evaluation, targets
+from . import coco_eval, evaluation, targets

@@ -129,3 +129,51 @@ def test_target_generators_properties():
     assert packed.shape == (2, 2, 17, 3) and counts.tolist() == [2, 0] and np.array_equal(packed[0], j)
     with pytest.raises(IndexError):
         lossmod.pack_joints([np.array([[[64, 0, 1]] * 17])], 17, 64, 64)
+
+
+def _gt_person(img_id, ann_id, kpts, area, iscrowd=0):
+    k = np.asarray(kpts, np.float64)
+    x, y = k[:, 0], k[:, 1]
+    return {"image_id": img_id, "id": ann_id, "category_id": 1, "iscrowd": iscrowd, "area": area,
+            "num_keypoints": int((k[:, 2] > 0).sum()), "keypoints": k.reshape(-1).tolist(),
+            "bbox": [float(x.min()), float(y.min()), float(x.max() - x.min()), float(y.max() - y.min())]}
+
+
+def test_coco_oks_evaluator_hand_cases():
+    """OKS / AP restated from the published pycocotools algorithm (package absent here: hand-derived expectations)."""
+    ce = importlib.import_module(PKG + ".keypoints.coco_eval")
+    ev_mod = importlib.import_module(PKG + ".keypoints.evaluation")
+    rs = np.random.RandomState(0)
+    gts, dets = [], []
+    for img in (1, 2, 3):
+        for p in range(2):
+            k = np.concatenate([rs.uniform(50, 300, (17, 2)), np.full((17, 1), 2.0)], 1)
+            gts.append(_gt_person(img, 10 * img + p, k, area=150.0 ** 2))
+            dets += ev_mod.pack_coco_results(img, k[None, :, :2].astype(np.float32), np.array([0.9 - 0.1 * p], np.float32))
+    ev = ce.COCOKeypointsEval(gts, dets)
+    st = ev.evaluate()
+    assert np.allclose(st[[0, 1, 2, 4, 5, 6, 7, 9]], 1.0) and st[3] == -1 and st[8] == -1  # all "large": medium has no gt
+    # a known OKS: every joint displaced by d pixels -> OKS = mean(exp(-d^2 / (2 (2 sigma)^2 area)))
+    d, area = 12.0, 150.0 ** 2
+    shifted = []
+    for g in gts:
+        k = np.asarray(g["keypoints"]).reshape(17, 3)
+        shifted.append({"image_id": g["image_id"], "category_id": 1, "score": 0.5,
+                        "keypoints": np.concatenate([k[:, :2] + [d, 0.0], np.ones((17, 1))], 1).reshape(-1).tolist()})
+    ev2 = ce.COCOKeypointsEval(gts, shifted)
+    oks = ev2._oks(1)
+    expect = np.mean(np.exp(-(d * d) / ((2 * ce.KPT_OKS_SIGMAS) ** 2) / (area + np.spacing(1)) / 2))
+    assert abs(oks[0, 0] - expect) < 1e-12 or abs(oks[1, 1] - expect) < 1e-12
+    st2 = ev2.evaluate()
+    n_thr = int((ce.IOU_THRS <= expect + 1e-12).sum())  # matched at every threshold <= OKS, unmatched above
+    assert abs(st2[0] - n_thr / 10.0) < 1e-9 and abs(st2[5] - n_thr / 10.0) < 1e-9
+    # false positives ranked above the true ones halve the precision at every recall level
+    fp = [dict(x, score=0.99, keypoints=(np.asarray(x["keypoints"]) + 1000).tolist()) for x in dets]
+    st3 = ce.COCOKeypointsEval(gts, dets + fp).evaluate()
+    assert abs(st3[0] - 0.5) < 0.02 and abs(st3[5] - 1.0) < 1e-9
+    # crowd ground truth is ignored (its detection is neither TP nor FP); more than 20 detections per image are cut
+    crowd = [dict(g, iscrowd=1) if i == 0 else g for i, g in enumerate(gts)]
+    st4 = ce.COCOKeypointsEval(crowd, dets).evaluate()
+    assert abs(st4[0] - 1.0) < 1e-9
+    many = dets + [dict(dets[0], score=0.01 * i) for i in range(1, 40)]
+    assert len(ce.COCOKeypointsEval(gts, many)._oks(1)) == 20
