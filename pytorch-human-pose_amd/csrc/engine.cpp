@@ -490,7 +490,6 @@ int hh_net::finalize()
         l.cin_pad = round_up(l.cin, l.KC);
         const int COUT_T = 32 * l.NT;
         l.ncg = coutp / COUT_T;
-        const int nch = l.cin_pad / l.KC, taps = l.ks * l.ks, C8 = l.KC / 8;
         const std::vector<float> &W = get(l.conv + ".weight");
         std::vector<float> scale(coutp, 0.f), shift(coutp, 0.f);
         for (int co = 0; co < l.cout; ++co) {
@@ -652,9 +651,6 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             HH_CHECK_HIP(hipStreamWaitEvent(L[op.lane], e, 0));
             break;
         }
-        case OP_INCONVERT:
-            HH_CHECK_HIP(launch_in_convert(images, tensors[op.out].ptr, B, H, W, s));
-            break;
         case OP_STEM: {
             const ConvLayer &l = layers[op.layer];
             StemParams p{};

@@ -47,7 +47,7 @@ struct TensorDesc {
     bool zero_init = false;
 };
 
-enum OpKind { OP_INCONVERT, OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC, OP_STEM };
+enum OpKind { OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC, OP_STEM };
 
 struct Op {
     OpKind kind = OP_CONV;

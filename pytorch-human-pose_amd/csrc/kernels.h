@@ -103,8 +103,6 @@ struct StemParams {
 #define HH_CFG_STEM 102  // pseudo instantiation index used by the profiler
 hipError_t stem_conv_launch(const StemParams &p, hipStream_t s);
 
-// fp32 NCHW [B,3,H,W] -> bf16 NHWC [B,H,W,16] (channels 3..15 zero)
-hipError_t launch_in_convert(const float *in, bf16_raw *out, int B, int H, int W, hipStream_t s);
 
 // out[b,y,x,c] = act(base[b,y,x,c] + sum_j up_j[b, y>>sh_j, x>>sh_j, c]),  c in [0,C)
 struct UpAddParams {

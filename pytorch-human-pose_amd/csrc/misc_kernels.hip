@@ -1,5 +1,5 @@
-// HBM-bound helper kernels of the forward path: input layout conversion, the fused
-// "nearest-upsample + n-way sum + ReLU" of the exchange (fusion) layers, flip TTA.
+// HBM-bound helper kernels of the forward path: the fused "nearest-upsample + n-way sum + ReLU" of the
+// exchange (fusion) layers, flip TTA, classifier tail, preprocessing.
 #include "kernels.h"
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -12,31 +12,6 @@ __device__ __forceinline__ unsigned pack2(float a, float b)
 }
 __device__ __forceinline__ float lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-
-// images fp32 NCHW [B,3,H,W] (what InferenceKeypointsModel.prepare_input hands over,
-// keypoints/model.py:70-76) -> bf16 NHWC with 16 channels so the stem conv is an MFMA k-step.
-__global__ __launch_bounds__(256) void in_convert_kernel(const float *__restrict__ in, bf16_raw *__restrict__ out, int B,
-                                                         int HW)
-{
-    const size_t total = (size_t)B * HW;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t b = i / HW, p = i % HW;
-        const float *src = in + b * 3 * HW + p;
-        uint4 v0 = make_uint4(pack2(src[0], src[HW]), pack2(src[2 * (size_t)HW], 0.f), 0, 0);
-        uint4 *dst = reinterpret_cast<uint4 *>(out + i * 16);
-        dst[0] = v0;
-        dst[1] = make_uint4(0, 0, 0, 0);
-    }
-}
-
-hipError_t launch_in_convert(const float *in, bf16_raw *out, int B, int H, int W, hipStream_t s)
-{
-    const size_t total = (size_t)B * H * W;
-    unsigned grid = (unsigned)((total + 255) / 256);
-    if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(in_convert_kernel, dim3(grid), dim3(256), 0, s, in, out, B, H * W);
-    return hipGetLastError();
-}
 
 // FusionLayer.forward's low->high terms and the sum (hrnet.py:200-205,214-229): the 1x1
 // conv + BN ran at low resolution; here the nearest upsample is an index shift on read and the
