@@ -42,14 +42,17 @@ def collect_profile(pkg, net):
     launch stream; kms = the same launches timed by the kernel itself on the device wall clock (first workgroup start
     to last workgroup end), which is what rocprofv3's kernel trace reports."""
     per_cfg = {}
-    cfg, flops, ms, kms, name = C.c_int(), C.c_double(), C.c_float(), C.c_float(), C.c_char_p()
+    cfg, flops, nbytes, ms, kms, name = C.c_int(), C.c_double(), C.c_double(), C.c_float(), C.c_float(), C.c_char_p()
     for i in range(n):
-        pkg._lib.check(lib.hh_profile_get(net._h, i, C.byref(cfg), C.byref(flops), C.byref(ms), C.byref(kms), C.byref(name)))
-        d = per_cfg.setdefault(cfg.value, {"n": 0, "ms": 0.0, "kms": 0.0, "flops": 0.0})
+        pkg._lib.check(lib.hh_profile_get(net._h, i, C.byref(cfg), C.byref(flops), C.byref(nbytes), C.byref(ms), C.byref(kms), C.byref(name)))
+        d = per_cfg.setdefault(cfg.value, {"n": 0, "ms": 0.0, "kms": 0.0, "flops": 0.0, "bytes": 0.0, "ceil_s": 0.0})
         d["n"] += 1
         d["ms"] += ms.value
         d["kms"] += kms.value if kms.value > 0 else ms.value
         d["flops"] += flops.value
+        d["bytes"] += nbytes.value
+        # roofline time of this launch: max(FLOPs / MFMA peak, algorithmic bytes / HBM peak)
+        d["ceil_s"] += max(flops.value / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), nbytes.value / (HBM_PEAK_GBS * 1e9))
     return per_cfg
 
 
@@ -260,6 +263,13 @@ def main():
                 "timing": "device wall clock inside the kernel (first workgroup start to last workgroup end), last timed step, "
                           "kernels serialised on one stream; HIP-event bracket of the same launches alongside",
                 "avg_launch_gflop": round(d["flops"] / d["n"] / 1e9, 3),
+                # the same launches against the HBM side of the roofline: algorithmic bytes (input + output + residual +
+                # weights, once each) over the same durations, and the two-sided ceiling min(MFMA peak, AI x HBM peak)
+                "avg_launch_mbytes": round(d["bytes"] / d["n"] / 1e6, 2),
+                "achieved_hbm_gbs": round(d["bytes"] / (d["kms"] * 1e-3) / 1e9, 1),
+                "hbm_frac": round(d["bytes"] / (d["kms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "roofline_ceiling_tflops": round(d["flops"] / d["ceil_s"] / 1e12, 1),
+                "frac_of_ceiling": round(d["ceil_s"] / (d["kms"] * 1e-3), 4),
                 "share_of_conv_time": round(d["kms"] / total_ms, 3),
                 "all_conv_tflops": round(sum(v["flops"] for v in per_cfg.values()) / (total_ms * 1e-3) / 1e12, 2),
             }

@@ -76,7 +76,8 @@ double hh_forward_flops(const hh_net *net, int B, int H, int W);
 
 /* Live per-launch timing for bench.py's roofline line: when enabled, hh_forward runs eagerly and brackets
  * every convolution launch with HIP events recorded on `stream`.  hh_profile_get(i) returns the i-th
- * launch since hh_profile_enable: kernel instantiation index, algorithmic FLOPs (2*MACs) of that launch,
+ * launch since hh_profile_enable: kernel instantiation index, algorithmic FLOPs (2*MACs) and bytes (input + output
+ * (+ residual) + weights, each once: no halo re-reads) of that launch,
  * elapsed milliseconds, and the state-dict prefix of the layer.  hh_conv_config describes an
  * instantiation as {KS, S, KC, NT, WC, PT, TW}.  `ms` is the HIP-event bracket (it includes the two
  * marker packets and the dispatch gap, ~4 us); `kernel_ms` is first-workgroup-start to last-workgroup-end
@@ -84,7 +85,7 @@ double hh_forward_flops(const hh_net *net, int B, int H, int W);
  * rocprofv3's kernel trace reports; -1 when unavailable.                                                */
 int hh_profile_enable(hh_net *net, int enable);
 int hh_profile_count(const hh_net *net);
-int hh_profile_get(hh_net *net, int index, int *cfg, double *flops, float *ms, float *kernel_ms, const char **layer);
+int hh_profile_get(hh_net *net, int index, int *cfg, double *flops, double *bytes, float *ms, float *kernel_ms, const char **layer);
 int hh_conv_config(int cfg, int out[7]);
 
 /* Kernel micro-benchmark used by tools/conv_bench.py (not on the hot path): `iters` back-to-back launches of

@@ -102,13 +102,13 @@ int hh_tap_read(hh_net *net, int index, float *host_nchw) { return hh_tap_read_i
 
 int hh_profile_enable(hh_net *net, int enable) { net->prof_enabled = enable != 0; net->prof_used = 0; return 0; }
 int hh_profile_count(const hh_net *net) { return (int)net->prof_used; }
-int hh_profile_get(hh_net *net, int i, int *cfg, double *flops, float *ms, float *kernel_ms, const char **layer)
+int hh_profile_get(hh_net *net, int i, int *cfg, double *flops, double *bytes, float *ms, float *kernel_ms, const char **layer)
 {
     if (i < 0 || i >= (int)net->prof_used) { hh_set_error("hh_profile_get: index out of range"); return 1; }
     const ProfRecord &r = net->prof[i];
     HH_CHECK_HIP(hipEventSynchronize(r.e1));
     HH_CHECK_HIP(hipEventElapsedTime(ms, r.e0, r.e1));
-    *cfg = r.cfg; *flops = r.flops;
+    *cfg = r.cfg; *flops = r.flops; *bytes = r.bytes;
     *layer = net->layers[net->ops[r.op].layer].conv.c_str();
     *kernel_ms = -1.f;
     if (r.slot >= 0 && net->d_clk && net->clk_khz > 0) {

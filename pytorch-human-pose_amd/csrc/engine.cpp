@@ -669,6 +669,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->op = (int)(&op - ops.data());
                 pr->cfg = HH_CFG_STEM;
                 pr->flops = 2.0 * B * (H / 2) * (W / 2) * 27.0 * 64.0;
+                pr->bytes = (double)B * H * W * 3 * 4 + (double)B * (H / 2) * (W / 2) * 64 * 2 + 64 * 32 * 2;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
                 if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
                 HH_CHECK_HIP(hipEventRecord(pr->e0, s));
@@ -734,6 +735,8 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->op = (int)(&op - ops.data());
                 pr->cfg = HH_CFG_JUNCTION;
                 pr->flops = 2.0 * p.npix * 64.0 * 256.0 * (1 + (op.in2 >= 0) + (op.layer3 >= 0));
+                pr->bytes = 2.0 * p.npix * (64 + (op.in2 >= 0 ? 64 : 256) + 256 + (op.layer3 >= 0 ? 64 : 0)) +
+                            2.0 * 64 * 256 * (1 + (op.in2 >= 0) + (op.layer3 >= 0));
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
                 if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
                 HH_CHECK_HIP(hipEventRecord(pr->e0, s));
@@ -763,6 +766,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
                 if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
                 pr->flops = 2.0 * 2.0 * B * p.H * p.W * 32.0 * 32.0 * 9.0;
+                pr->bytes = 2.0 * B * p.H * p.W * 32 * 2 + 2.0 * 2 * 9 * 32 * 32;
                 HH_CHECK_HIP(hipEventRecord(pr->e0, s));
             }
             HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
@@ -819,6 +823,11 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
                 if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
                 pr->flops = 2.0 * B * p.Ho * p.Wo * (double)l.cin * l.cout * l.ks * l.ks * (p.nphase > 1 ? 4 : 1);
+                {
+                    const double opix = (double)B * p.Ho * p.Wo * (p.nphase > 1 ? 4 : 1);
+                    pr->bytes = 2.0 * B * p.Hin * p.Win * l.cin + (p.out ? 2.0 * opix * l.cout : 0.0) + (p.res ? 2.0 * opix * l.cout : 0.0) +
+                                (p.out_f32 ? 4.0 * opix * l.cout : 0.0) + 2.0 * l.cin * l.cout * l.ks * l.ks * (p.nphase > 1 ? 4 : 1);
+                }
                 HH_CHECK_HIP(hipEventRecord(pr->e0, s));
             }
             HH_CHECK_HIP(conv_launch(cfg, p, s));

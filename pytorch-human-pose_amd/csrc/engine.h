@@ -77,7 +77,7 @@ struct TapInfo {
 
 struct ProfRecord {
     int op, cfg;
-    double flops;
+    double flops, bytes;  // algorithmic: 2*MACs; input + output (+ residual) + weights once, no halo re-reads
     hipEvent_t e0, e1;
     int slot;  // index into d_clk ({min start, max end} device-clock ticks written by the kernel itself), -1 = none
 };

@@ -21,17 +21,19 @@ n = lib.hh_profile_count(net._h)
 cfg, fl, ms, name = C.c_int(), C.c_double(), C.c_float(), C.c_char_p()
 agg = collections.OrderedDict()
 for i in range(n):
-    kms = C.c_float()
-    lib.hh_profile_get(net._h, i, C.byref(cfg), C.byref(fl), C.byref(ms), C.byref(kms), C.byref(name))
+    kms, by = C.c_float(), C.c_double()
+    lib.hh_profile_get(net._h, i, C.byref(cfg), C.byref(fl), C.byref(by), C.byref(ms), C.byref(kms), C.byref(name))
     nm = name.value.decode()
     key = re.sub(r"blocks\.\d+\.scales_blocks\.(\d+)\.\d+", r"blocks.*.scales_blocks.\1.*", nm)
     key = re.sub(r"blocks\.\d+\.scales_fusion", "blocks.*.scales_fusion", key)
     key = re.sub(r"resid_blocks\.\d+", "resid_blocks.*", key)
-    d = agg.setdefault((key, cfg.value), [0, 0.0, 0.0])
-    d[0] += 1; d[1] += (kms.value if kms.value > 0 else ms.value); d[2] += fl.value
+    d = agg.setdefault((key, cfg.value), [0, 0.0, 0.0, 0.0])
+    d[0] += 1; d[1] += (kms.value if kms.value > 0 else ms.value); d[2] += fl.value; d[3] += by.value
 tot = sum(v[1] for v in agg.values()) / R
 print(f"conv total {tot:.3f} ms per forward (B={B}), {sum(v[2] for v in agg.values())/R/tot/1e9:.1f} TFLOP/s")
 cv = (C.c_int * 7)()
-for (key, c), (cnt, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+for (key, c), (cnt, t, f, by_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     lib.hh_conv_config(c, cv)
-    print(f"{t/R:8.3f} ms  {cnt//R:3d}x {t/cnt*1e3:8.1f} us  {f/t/1e9:7.1f} TF/s  cfg{tuple(cv)}  {key}")
+    ai = f / by_
+    ceil = min(2500.0, ai * 8.0)  # roofline ceiling in TFLOP/s: min(MFMA peak, AI x 8 TB/s)
+    print(f"{t/R:8.3f} ms  {cnt//R:3d}x {t/cnt*1e3:8.1f} us  {f/t/1e9:7.1f} TF/s  {by_/t/1e9:6.2f} TB/s  AI {ai:5.0f}  ceiling {ceil:6.0f} ({f/t/1e9/ceil*100:3.0f}%)  cfg{tuple(cv) if c < 100 else c}  {key}")
