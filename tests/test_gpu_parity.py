@@ -391,3 +391,42 @@ def test_ae_loss_and_gradients_match_reference(pkg):
         lossmod.AEGroupingLoss()(t, [np.array([[[8, 1, 1]] * 17], np.int32)])
     with pytest.raises(pkg._lib.HHError):
         lossmod.HeatmapsLoss()(torch.zeros(1, 17, 8, 8), torch.zeros(1, 17, 8, 8), torch.ones(1, 8, 8))
+
+
+def test_full_size_properties_batch32_512(pkg):
+    """BASELINE.json configs[1] at its full size (B=32, 512x512, W32), where the CPU oracle would take minutes: size-independent
+    properties instead.  (i) images are independent: row b of a batched forward is bit-identical to the forward of image b alone,
+    and repeated runs are bit-identical; (ii) decode of a batch equals decode of each image alone; (iii) top-k scores come out
+    sorted, are local 5x5 maxima of the aggregated map and no joint of a decoded person lies outside the image."""
+    net, _ = _net(pkg, 32, 0)
+    B, H, W, K = 32, 512, 512, 17
+    x = torch.from_numpy(pkg.synth.synth_images(B, H, W, seed=3)).to(DEV)
+    init, dec = net.forward_raw(x)
+    init2, dec2 = net.forward_raw(x)
+    assert torch.equal(init, init2) and torch.equal(dec, dec2)
+    assert torch.isfinite(init).all() and torch.isfinite(dec).all()
+    for b in (0, 13, 31):
+        i1, d1 = net.forward_raw(x[b:b + 1].contiguous())
+        assert torch.equal(i1[0], init[b]) and torch.equal(d1[0], dec[b])
+    uniq = [pkg.synth.synth_decode_maps(K, H // 4, W // 4, 10, seed=2000 + i)[:3] for i in range(4)]
+    hm_q = torch.from_numpy(np.stack([uniq[i % 4][0] for i in range(B)])).to(DEV)
+    hm_h = torch.from_numpy(np.stack([uniq[i % 4][1] for i in range(B)])).to(DEV)
+    tags = torch.from_numpy(np.stack([uniq[i % 4][2][0] for i in range(B)])).to(DEV)
+    parser = pkg.MPPEHeatmapParser(K, 30, 0.05, 0.5)
+    joints, scores, num = [t.clone() for t in parser.decode_batch_device(hm_q, hm_h, [tags])]
+    _, _, sk = parser.last_top_k(B, 1)
+    assert np.all(np.diff(sk, axis=-1) <= 0)  # per joint: candidates in descending score order
+    n = num.cpu().numpy()
+    assert n.min() >= 1 and n.max() <= 30
+    j = joints.cpu().numpy()
+    for b in range(B):
+        p = j[b, : n[b]]
+        seen = p[..., 2] > 0
+        assert np.all(p[..., 0][seen] >= 0) and np.all(p[..., 0][seen] < W) and np.all(p[..., 1][seen] >= 0) and np.all(p[..., 1][seen] < H)
+        assert np.array_equal(j[b], j[b % 4]) and n[b] == n[b % 4]  # the batch repeats 4 distinct images
+    for b in (0, 5):
+        j1, s1, n1 = parser.decode_batch_device(hm_q[b:b + 1], hm_h[b:b + 1], [tags[b:b + 1]])
+        assert int(n1[0]) == int(n[b]) and torch.equal(j1[0], joints[b]) and torch.equal(s1[0], scores[b])
+    # the oracle agrees on one of the full-size images (takes ~0.3 s per image)
+    rj, rs = orc.decode(uniq[0][0], uniq[0][1], [uniq[0][2][0]], max_people=30, det_thr=0.05, tag_thr=0.5)
+    assert np.array_equal(j[0, : n[0]], rj) and np.array_equal(scores[0, : n[0]].cpu().numpy(), rs)
