@@ -71,6 +71,10 @@ int hh_forward(hh_net *net, const float *images, int B, int H, int W, float *ini
  * internal HIP streams forked from and joined back to `stream` with events.  0 = everything on `stream`. */
 int hh_set_multi_lane(hh_net *net, int enable);
 
+/* Static check of the multi-lane schedule (no GPU needed): every read-after-write, write-after-read and write-after-write
+ * pair of ops on different lanes must be ordered by a join/dependency edge.  0 = no hazard.                              */
+int hh_debug_check_plan(const hh_net *net);
+
 /* Algorithmic conv/deconv FLOPs (2*MACs) of one forward at this shape -- SURVEY.md §8d.  */
 double hh_forward_flops(const hh_net *net, int B, int H, int W);
 

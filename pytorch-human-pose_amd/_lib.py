@@ -68,6 +68,7 @@ def _sig(lib):
         "hh_decoder_reserve": (i32, [vp, i32, i32, i32, i32]),
         "hh_decode": (i32, [vp, vp, i64, vp, i64, vp, pi64, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
         "hh_parse": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+        "hh_debug_check_plan": (i32, [vp]),
         "hh_loss_heatmaps": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, i64, vp, vp]),
         "hh_loss_ae_grouping": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, vp, i64, C.c_float, C.c_float, vp, vp]),
         "hh_resize_accumulate": (i32, [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, C.c_float, i32, vp]),

@@ -100,6 +100,13 @@ int hh_tap_shape(const hh_net *net, int i, int64_t shape[4])
 }
 int hh_tap_read(hh_net *net, int index, float *host_nchw) { return hh_tap_read_impl(net, index, host_nchw); }
 
+int hh_debug_check_plan(const hh_net *net)
+{
+    std::string why;
+    if (net->check_plan(&why)) { hh_set_error("schedule hazard: " + why); return 1; }
+    return 0;
+}
+
 int hh_profile_enable(hh_net *net, int enable) { net->prof_enabled = enable != 0; net->prof_used = 0; return 0; }
 int hh_profile_count(const hh_net *net) { return (int)net->prof_used; }
 int hh_profile_get(hh_net *net, int i, int *cfg, double *flops, double *bytes, float *ms, float *kernel_ms, const char **layer)

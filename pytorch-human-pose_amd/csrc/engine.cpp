@@ -880,6 +880,76 @@ int hh_net::forward(const float *images, int B, int H, int W, float *o1, float *
     return 0;
 }
 
+// Static hazard check of the multi-lane plan: replays the fork/join/dep edges of enqueue() with vector clocks (one
+// component per lane) and verifies for every op that (RAW) the last writer of each tensor it reads, and (WAR/WAW) every
+// earlier reader and the last writer of each tensor it writes, happen-before it.  Ops of one lane are ordered by the stream.
+int hh_net::check_plan(std::string *why) const
+{
+    struct Stamp { int lane; int t; int op; };
+    int clk[4][4] = {};  // clk[l][m] = latest event of lane m that lane l is ordered after
+    auto before = [&](const Stamp &st, int lane) { return st.lane < 0 || clk[lane][st.lane] >= st.t; };
+    std::vector<Stamp> writer(tensors.size(), Stamp{-1, 0, -1});
+    std::vector<std::vector<Stamp>> readers(tensors.size());
+    int lanes_open = 1;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const Op &op = ops[i];
+        if (op.kind == OP_JOIN) {
+            const int nrec = op.nlanes < lanes_open ? op.nlanes : lanes_open;
+            int merged[4] = {};
+            for (int m = 0; m < nrec; ++m)
+                for (int c = 0; c < 4; ++c) merged[c] = std::max(merged[c], clk[m][c]);
+            for (int l = 0; l < op.nlanes; ++l)
+                for (int c = 0; c < 4; ++c) clk[l][c] = std::max(clk[l][c], merged[c]);
+            if (op.nlanes > lanes_open) lanes_open = op.nlanes;
+            continue;
+        }
+        if (op.kind == OP_DEP) {
+            for (int c = 0; c < 4; ++c) clk[op.lane][c] = std::max(clk[op.lane][c], clk[op.dep_from][c]);
+            continue;
+        }
+        const int l = op.lane;
+        if (l >= lanes_open) { if (why) *why = "op " + std::to_string(i) + " runs on a lane that was never forked"; return 1; }
+        std::vector<int> rd, wr;
+        switch (op.kind) {
+        case OP_CONV: rd = {op.in, op.res}; wr = {op.out}; break;
+        case OP_UPADD: rd = {op.in, op.up[0], op.up[1], op.up[2]}; wr = {op.out}; break;
+        case OP_BB: rd = {op.in}; wr = {op.out}; break;
+        case OP_JUNC: rd = {op.in, op.in2, op.res}; wr = {op.out, op.out2}; break;
+        case OP_STEM: wr = {op.out}; break;
+        case OP_TAP: continue;  // taps only run with the lanes switched off (enqueue: multi = ... && !taps_enabled)
+        case OP_AVGPOOL: rd = {op.in}; break;
+        default: break;
+        }
+        const int t = ++clk[l][l];
+        for (int x : rd) {
+            if (x < 0) continue;
+            if (!before(writer[x], l)) {
+                if (why) *why = "RAW: op " + std::to_string(i) + " (lane " + std::to_string(l) + ") reads tensor " + std::to_string(x) +
+                                " written by op " + std::to_string(writer[x].op) + " (lane " + std::to_string(writer[x].lane) + ") without an edge";
+                return 1;
+            }
+        }
+        for (int x : wr) {
+            if (x < 0) continue;
+            if (!before(writer[x], l)) {
+                if (why) *why = "WAW: op " + std::to_string(i) + " overwrites tensor " + std::to_string(x) + " of op " + std::to_string(writer[x].op);
+                return 1;
+            }
+            for (const Stamp &r : readers[x])
+                if (!(r.lane == l) && !before(r, l)) {
+                    if (why) *why = "WAR: op " + std::to_string(i) + " (lane " + std::to_string(l) + ") overwrites tensor " + std::to_string(x) +
+                                    " still read by op " + std::to_string(r.op) + " (lane " + std::to_string(r.lane) + ")";
+                    return 1;
+                }
+        }
+        for (int x : rd)
+            if (x >= 0) readers[x].push_back(Stamp{l, t, (int)i});
+        for (int x : wr)
+            if (x >= 0) { writer[x] = Stamp{l, t, (int)i}; readers[x].clear(); }
+    }
+    return 0;
+}
+
 double hh_net::flops(int B, int H, int W) const
 {
     double macs = 0;

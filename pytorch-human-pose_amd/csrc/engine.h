@@ -122,6 +122,7 @@ struct hh_net {
     bool multi_lane = true;
 
     int build();
+    int check_plan(std::string *why) const;  // static RAW/WAR/WAW check of the multi-lane schedule
     int add_param(const std::string &name, std::vector<int64_t> shape, bool counter = false);
     int finalize();
     int reserve(int B, int H, int W);

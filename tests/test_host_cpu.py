@@ -177,3 +177,11 @@ def test_coco_oks_evaluator_hand_cases():
     assert abs(st4[0] - 1.0) < 1e-9
     many = dets + [dict(dets[0], score=0.01 * i) for i in range(1, 40)]
     assert len(ce.COCOKeypointsEval(gts, many)._oks(1)) == 20
+
+
+def test_multi_lane_schedule_has_no_unordered_hazard(pkg):
+    """hh_debug_check_plan replays the fork/join/dependency edges of the multi-stream schedule with vector clocks: every
+    RAW / WAR / WAW pair of ops on different lanes must be ordered (it reports the transition-conv race this repo once had)."""
+    lib = pkg._lib.load()
+    for net in (pkg.HigherHRNet(17, 32), pkg.HigherHRNet(17, 48), pkg.HigherHRNet(5, 32), pkg.ClassificationHRNet(32, 10)):
+        assert lib.hh_debug_check_plan(net._h) == 0, lib.hh_last_error().decode()
