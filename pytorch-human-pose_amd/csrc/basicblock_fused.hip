@@ -104,12 +104,6 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fused_kernel(const BBParams p)
     const int wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
 
-    // ---- both weight sets: loaded once per workgroup
-    for (int u = tid; u < W_UNITS; u += NTHR) {
-        reinterpret_cast<u32x4 *>(lds_w1)[u] = reinterpret_cast<const u32x4 *>(p.w1)[u];
-        reinterpret_cast<u32x4 *>(lds_w2)[u] = reinterpret_cast<const u32x4 *>(p.w2)[u];
-    }
-    if (tid < 32) { lds_b[tid] = p.b1[tid]; lds_b[32 + tid] = p.b2[tid]; }
     // identity A fragments (rows = couts, k = cin): frag kk has A[r][k] = 1 where 16*kk + k == r
     u32x4 ident[2];
 #pragma unroll
@@ -177,7 +171,13 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fused_kernel(const BBParams p)
 
     int t = blockIdx.x;
     pf_setup(t);
-    static_for<NPL>(pf_load);
+    static_for<NPL>(pf_load);  // the first patch is in flight while the weights arrive (one exposed latency, not two)
+    // ---- both weight sets: loaded once per workgroup
+    for (int u = tid; u < W_UNITS; u += NTHR) {
+        reinterpret_cast<u32x4 *>(lds_w1)[u] = reinterpret_cast<const u32x4 *>(p.w1)[u];
+        reinterpret_cast<u32x4 *>(lds_w2)[u] = reinterpret_cast<const u32x4 *>(p.w2)[u];
+    }
+    if (tid < 32) { lds_b[tid] = p.b1[tid]; lds_b[32 + tid] = p.b2[tid]; }
     static_for<NPL>(write_patch_unit);
     __syncthreads();
 
