@@ -166,6 +166,26 @@ int hh_loss_ae_grouping(const float *tags, int64_t tags_bstride, const int32_t *
                         int h, int w, float *push_pull, float *grad, int64_t grad_bstride, float push_scale, float pull_scale,
                         double *scratch, void *stream);
 
+/* Building blocks of the training step (keypoints/module.py:43-71; not yet assembled into a net: conv weight gradients,
+ * stride-2 data gradients and the optimizer are missing).  Activations are NHWC bf16 [B,H,W,C] (= torch channels_last),
+ * parameters fp32, all device pointers.
+ *
+ * hh_conv2d: y = act(conv(x, w) + bias (+ res)) with the CURRENT fp32 weights w [cout][cin][ks][ks] (packed on the device
+ *   each call), ks in {1,3}, stride in {1,2}, padding (ks-1)/2.  mode 1 = data gradient of the stride-1 conv with these
+ *   weights: x is dL/dy [B,H,W,cout], y is dL/dx [B,H,W,cin] (the same kernel with rotated, transposed weights).
+ *   Input channels (of the conv that runs) % 16 == 0, output channels % 8 == 0; workspace: hh_conv2d_workspace_bytes.
+ * hh_bn_train_forward = nn.BatchNorm2d in training mode on [P = B*H*W, C] (+ residual, + ReLU): batch mean and biased
+ *   variance, y = act(gamma * (x - mean) * invstd + beta (+ res)); mean / invstd are kept for the backward.
+ *   scratch: 256 * C * 2 doubles.  (The running statistics are updated by the caller: plain torch arithmetic on C floats.)
+ * hh_bn_train_backward: dx, dgamma, dbeta (and dres = the gradient after the ReLU mask, if dres != NULL).               */
+int64_t hh_conv2d_workspace_bytes(int cin, int cout, int ks, int mode);
+int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int cout, int ks, int stride, int mode, const float *bias,
+              const void *res, int relu, void *y, void *workspace, void *stream);
+int hh_bn_train_forward(const void *x, int64_t P, int C, const float *gamma, const float *beta, float eps, const void *res, int relu,
+                        void *y, float *mean, float *invstd, double *scratch, void *stream);
+int hh_bn_train_backward(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd,
+                         const float *gamma, int relu, void *dx, void *dres, float *dgamma, float *dbeta, double *scratch, void *stream);
+
 /* Multi-scale test-time augmentation (BASELINE.json configs[3]; an extension: the reference only calls its resize helper
  * with scale 1, keypoints/model.py:73): dst[B,K,H,W] (+)= weight * bilinear(src[B,K,h,w] -> HxW) with the arithmetic of
  * F.interpolate(mode="bilinear", align_corners=False); init != 0 overwrites dst.  Batch strides in elements.            */

@@ -71,6 +71,10 @@ def _sig(lib):
         "hh_debug_check_plan": (i32, [vp]),
         "hh_loss_heatmaps": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, i64, vp, vp]),
         "hh_loss_ae_grouping": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, vp, i64, C.c_float, C.c_float, vp, vp]),
+        "hh_conv2d_workspace_bytes": (i64, [i32, i32, i32, i32]),
+        "hh_conv2d": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp]),
+        "hh_bn_train_forward": (i32, [vp, i64, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, vp, vp]),
+        "hh_bn_train_backward": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
         "hh_resize_accumulate": (i32, [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, C.c_float, i32, vp]),
         "hh_decoder_read_topk": (i32, [vp, vp, vp, vp]),
         "hh_transform_coords": (i32, [vp, i32, dbl, dbl, dbl, dbl, dbl, vp]),

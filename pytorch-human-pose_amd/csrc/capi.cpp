@@ -161,6 +161,74 @@ int hh_loss_ae_grouping(const float *tags, int64_t tags_bstride, const int32_t *
     return 0;
 }
 
+// ------------------------------------------------------------------ training building blocks
+static int round_up_i(int a, int b) { return (a + b - 1) / b * b; }
+
+int64_t hh_conv2d_workspace_bytes(int cin, int cout, int ks, int mode)
+{
+    const int ci = mode ? cout : cin, co = mode ? cin : cout;
+    const int coutp = round_up_i(co, 32);
+    int KC = 0, NT = 0;
+    if (hh_family_pick(ks, 1, round_up_i(ci, 16), coutp, &KC, &NT)) return -1;
+    const int cin_pad = round_up_i(ci, KC);
+    return (int64_t)coutp * cin_pad * ks * ks * 2 + (int64_t)coutp * 4 + 256;
+}
+
+int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int cout, int ks, int stride, int mode, const float *bias,
+              const void *res, int relu, void *y, void *workspace, void *stream)
+{
+    static bool inited = false;
+    if (!inited) { HH_CHECK_HIP(conv_init()); inited = true; }
+    const int ci = mode ? cout : cin, co = mode ? cin : cout;  // channels of the conv that actually runs
+    if (!x || !w || !y || !workspace || B <= 0 || H <= 0 || W <= 0) { hh_set_error("hh_conv2d: bad argument"); return 1; }
+    if (ci % 16 || co % 8) { hh_set_error("hh_conv2d: input channels must be a multiple of 16 and output channels of 8"); return 1; }
+    if (mode && stride != 1) { hh_set_error("hh_conv2d: the data-gradient mode covers stride-1 convolutions"); return 1; }
+    const int coutp = round_up_i(co, 32);
+    int KC = 0, NT = 0;
+    if (hh_family_pick(ks, stride, ci, coutp, &KC, &NT)) { hh_set_error("hh_conv2d: no kernel family for this shape"); return 1; }
+    const int COUT_T = 32 * NT, cin_pad = round_up_i(ci, KC);
+    const size_t wel = (size_t)coutp * cin_pad * ks * ks;
+    bf16_raw *packed = (bf16_raw *)workspace;
+    float *zbias = (float *)((char *)workspace + ((wel * 2 + 255) & ~(size_t)255));
+    hipStream_t s = (hipStream_t)stream;
+    HH_CHECK_HIP(launch_pack_weights(w, cout, cin, ks, mode, KC, COUT_T, packed, wel, s));
+    if (bias) HH_CHECK_HIP(hipMemcpyAsync(zbias, bias, (size_t)co * 4, hipMemcpyDeviceToDevice, s));
+    else HH_CHECK_HIP(hipMemsetAsync(zbias, 0, (size_t)coutp * 4, s));
+    const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
+    const int cfg = hh_pick_config(ks, stride, KC, NT, Wo);
+    if (cfg < 0) { hh_set_error("hh_conv2d: no kernel instantiation for this shape"); return 1; }
+    const ConvConfig &cc = conv_config(cfg);
+    ConvParams p{};
+    p.in = (const bf16_raw *)x; p.in_cs = ci; p.Hin = H; p.Win = W;
+    p.w = packed; p.bias = zbias;
+    p.res = (const bf16_raw *)res; p.res_cs = co;
+    p.out = (bf16_raw *)y; p.out_cs = co;
+    p.Ho = Ho; p.Wo = Wo; p.Hob = Ho; p.Wob = Wo; p.osy = p.osx = 1;
+    p.cin = cin_pad; p.cout_real = co; p.cout_store = co; p.relu = relu;
+    p.pad_y = p.pad_x = (ks - 1) / 2; p.B = B;
+    p.tiles_x = (Wo + cc.TW - 1) / cc.TW; p.tiles_y = (Ho + cc.th() - 1) / cc.th(); p.ncg = coutp / cc.cout_t();
+    HH_CHECK_HIP(conv_launch(cfg, p, s));
+    return 0;
+}
+
+int hh_bn_train_forward(const void *x, int64_t P, int C, const float *gamma, const float *beta, float eps, const void *res, int relu,
+                        void *y, float *mean, float *invstd, double *scratch, void *stream)
+{
+    if (!x || !y || !gamma || !beta || !mean || !invstd || !scratch || P <= 0 || C <= 0 || C % 8 || C > 2048) { hh_set_error("hh_bn_train_forward: bad argument (C must be a multiple of 8, <= 2048)"); return 1; }
+    HH_CHECK_HIP(launch_bn_train_forward((const bf16_raw *)x, C, (size_t)P, C, gamma, beta, eps, (const bf16_raw *)res, relu, (bf16_raw *)y,
+                                         mean, invstd, scratch, (hipStream_t)stream));
+    return 0;
+}
+
+int hh_bn_train_backward(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd,
+                         const float *gamma, int relu, void *dx, void *dres, float *dgamma, float *dbeta, double *scratch, void *stream)
+{
+    if (!x || !y || !dy || !dx || !mean || !invstd || !gamma || !dgamma || !dbeta || !scratch || P <= 0 || C <= 0 || C % 8 || C > 2048) { hh_set_error("hh_bn_train_backward: bad argument"); return 1; }
+    HH_CHECK_HIP(launch_bn_train_backward((const bf16_raw *)x, (const bf16_raw *)y, (const bf16_raw *)dy, C, (size_t)P, C, mean, invstd, gamma,
+                                          relu, (bf16_raw *)dx, (bf16_raw *)dres, dgamma, dbeta, scratch, (hipStream_t)stream));
+    return 0;
+}
+
 int hh_flip_images(const float *images, float *out, int B, int C, int H, int W, void *stream)
 {
     HH_CHECK_HIP(launch_flip_images(images, out, B, C, H, W, (hipStream_t)stream));

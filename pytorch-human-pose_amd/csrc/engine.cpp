@@ -431,7 +431,7 @@ void hh_pack_weights(const float *W, const float *scale, int ks, int cin, int co
 }
 
 // ------------------------------------------------------------------------- finalize
-static int family_pick(int ks, int stride, int cin_pad, int coutp, int *KC, int *NT)
+int hh_family_pick(int ks, int stride, int cin_pad, int coutp, int *KC, int *NT)
 {
     if (ks == 3 && stride == 1) *KC = (cin_pad % 32 == 0) ? 32 : 16;
     else if (ks == 1) *KC = (cin_pad % 32 == 0) ? 32 : 16;
@@ -483,7 +483,7 @@ int hh_net::finalize()
             continue;
         }
         const int cin_pad0 = round_up(l.cin, 16), coutp = round_up(l.cout, 32);
-        if (family_pick(l.ks, l.stride, cin_pad0, coutp, &l.KC, &l.NT)) {
+        if (hh_family_pick(l.ks, l.stride, cin_pad0, coutp, &l.KC, &l.NT)) {
             hh_set_error("no kernel family for conv " + l.conv);
             return 1;
         }
@@ -581,6 +581,18 @@ int hh_net::reserve(int B, int H, int W)
 }
 
 // ------------------------------------------------------------------------- execution
+int hh_pick_config(int ks, int stride, int KC, int NT, int Wo)
+{
+    int best = -1;
+    for (int i = 0; i < conv_num_configs(); ++i) {
+        const ConvConfig &c = conv_config(i);
+        if (c.KS != ks || c.S != stride || c.KC != KC || c.NT != NT) continue;
+        if (best < 0) best = i;
+        const bool want16 = Wo <= 16;
+        if ((c.TW == 16) == want16) return i;
+    }
+    return best;
+}
 static int pick_config(const ConvLayer &l, int Wo)
 {
     int best = -1;

@@ -132,3 +132,7 @@ struct hh_net {
     void release_workspace();
     ~hh_net();
 };
+
+// kernel-family / instantiation choice, shared with the standalone conv op of the training path (capi.cpp)
+int hh_family_pick(int ks, int stride, int cin_pad, int coutp, int *KC, int *NT);
+int hh_pick_config(int ks, int stride, int KC, int NT, int Wo);

@@ -1,0 +1,235 @@
+// Building blocks of the training path (first half): convolution with *current* fp32 weights
+// (forward, and the data gradient of a stride-1 conv as a forward conv with rotated, transposed weights) and train-mode
+// BatchNorm forward / backward, all on NHWC bf16 activations.  The convolution itself is the conv_mfma family; what is
+// new here is packing the weights ON THE DEVICE every step (the inference engine packs once on the host at finalize).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace {
+__device__ __forceinline__ bf16_raw f2bf_dev(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+}
+
+// packed[cg][chunk][tap][c8][co_in][j]  <-  W, see hh_pack_weights (engine.cpp) for the host twin.
+//   mode 0: conv weights W[cout][cin][ks][ks]                      -> out channel o = co, in channel i = ci, tap (ky,kx)
+//   mode 1: data gradient of a stride-1 conv: the forward conv of dL/dy with W'[ci][co][ks-1-ky][ks-1-kx]
+//           (cout_eff = cin, cin_eff = cout)
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ W, int cout, int cin, int ks, int mode, int KC,
+                                                           int COUT_T, bf16_raw *__restrict__ packed, size_t total)
+{
+    const int co_eff = mode ? cin : cout, ci_eff = mode ? cout : cin;
+    const int cin_pad = (ci_eff + KC - 1) / KC * KC, nch = cin_pad / KC, taps = ks * ks, C8 = KC / 8;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        size_t r = o;
+        const int j = r % 8; r /= 8;
+        const int co_in = r % COUT_T; r /= COUT_T;
+        const int c8 = r % C8; r /= C8;
+        const int t = r % taps; r /= taps;
+        const int ch = r % nch; r /= nch;
+        const int cg = (int)r;
+        const int oc = cg * COUT_T + co_in, ic = ch * KC + c8 * 8 + j, ky = t / ks, kx = t % ks;
+        float v = 0.f;
+        if (oc < co_eff && ic < ci_eff)
+            v = mode ? W[(((size_t)ic * cin + oc) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)]   // W[co = ic][ci = oc][rot]
+                     : W[(((size_t)oc * cin + ic) * ks + ky) * ks + kx];
+        packed[o] = f2bf_dev(v);
+    }
+}
+
+hipError_t launch_pack_weights(const float *W, int cout, int cin, int ks, int mode, int KC, int COUT_T, bf16_raw *packed, size_t total,
+                               hipStream_t s)
+{
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, s, W, cout, cin, ks, mode, KC, COUT_T, packed, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ train-mode BatchNorm (nn.BatchNorm2d, training=True)
+// x [P, C] bf16 (P = B*H*W pixels, channel stride cs).  Statistics in fp32 with double partial sums in a fixed order.
+// stats kernel: partial[block][c] = {sum x, sum x^2} over the block's pixels; finalize: mean, biased var -> invstd.
+__global__ __launch_bounds__(256) void bn_partial_kernel(const bf16_raw *__restrict__ x, int cs, size_t P, int C, double *__restrict__ partial)
+{
+    // thread = (pixel lane pl = tid / C8, channel group g = tid % C8) over 8 channels; C % 8 == 0, C <= 2048
+    const int C8 = C / 8, g = threadIdx.x % C8, pl = threadIdx.x / C8, npl = 256 / C8;
+    double s[8] = {}, q[8] = {};
+    if (pl < npl)
+        for (size_t p = (size_t)blockIdx.x * npl + pl; p < P; p += (size_t)gridDim.x * npl) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + p * cs + g * 8);
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = __builtin_bit_cast(float, u[i] << 16), b = __builtin_bit_cast(float, u[i] & 0xffff0000u);
+                s[2 * i] += a; q[2 * i] += (double)a * a; s[2 * i + 1] += b; q[2 * i + 1] += (double)b * b;
+            }
+        }
+    __shared__ double sh[2][256][8 + 1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sh[0][threadIdx.x][i] = s[i]; sh[1][threadIdx.x][i] = q[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {  // fixed order over the pixel lanes
+        const int gg = c / 8, i = c % 8;
+        double a = 0, b = 0;
+        for (int l = 0; l < npl; ++l) { a += sh[0][l * C8 + gg][i]; b += sh[1][l * C8 + gg][i]; }
+        partial[((size_t)blockIdx.x * C + c) * 2] = a;
+        partial[((size_t)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+}
+__global__ void bn_finalize_kernel(const double *__restrict__ partial, int nblocks, int C, double P, float eps, float *__restrict__ mean,
+                                   float *__restrict__ invstd)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int i = 0; i < nblocks; ++i) { a += partial[((size_t)i * C + c) * 2]; b += partial[((size_t)i * C + c) * 2 + 1]; }
+    const double m = a / P, var = b / P - m * m;  // biased variance, as F.batch_norm normalises with
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+}
+// y = act(gamma * (x - mean) * invstd + beta (+ res))
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_raw *__restrict__ x, int cs, size_t P, int C, const float *__restrict__ mean,
+                                                       const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, const bf16_raw *__restrict__ res, int relu,
+                                                       bf16_raw *__restrict__ y)
+{
+    const int C8 = C / 8;
+    const size_t total = P * C8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t p = i / C8;
+        const int g = (int)(i % C8);
+        const uint4 v = *reinterpret_cast<const uint4 *>(x + p * cs + g * 8);
+        uint4 rv = make_uint4(0, 0, 0, 0);
+        if (res) rv = *reinterpret_cast<const uint4 *>(res + p * cs + g * 8);
+        const unsigned u[4] = {v.x, v.y, v.z, v.w}, ru[4] = {rv.x, rv.y, rv.z, rv.w};
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f[2] = {__builtin_bit_cast(float, u[k] << 16), __builtin_bit_cast(float, u[k] & 0xffff0000u)};
+            const float r[2] = {__builtin_bit_cast(float, ru[k] << 16), __builtin_bit_cast(float, ru[k] & 0xffff0000u)};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = g * 8 + 2 * k + h;
+                float t = (f[h] - mean[c]) * invstd[c] * gamma[c] + beta[c] + r[h];
+                f[h] = relu ? fmaxf(t, 0.f) : t;
+            }
+            o[k] = (unsigned)f2bf_dev(f[0]) | ((unsigned)f2bf_dev(f[1]) << 16);
+        }
+        *reinterpret_cast<uint4 *>(y + p * cs + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+hipError_t launch_bn_train_forward(const bf16_raw *x, int cs, size_t P, int C, const float *gamma, const float *beta, float eps,
+                                   const bf16_raw *res, int relu, bf16_raw *y, float *mean, float *invstd, double *scratch, hipStream_t s)
+{
+    const int nblocks = HH_BN_BLOCKS;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nblocks), dim3(256), 0, s, x, cs, P, C, scratch);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, nblocks, C, (double)P, eps, mean, invstd);
+    unsigned grid = (unsigned)((P * (C / 8) + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, s, x, cs, P, C, mean, invstd, gamma, beta, res, relu, y);
+    return hipGetLastError();
+}
+
+// Backward of y = act(gamma * xhat + beta (+ res)), xhat = (x - mean) * invstd:
+//   g = dy * (y > 0 if relu);  dbeta = sum g;  dgamma = sum g * xhat;
+//   dx = gamma * invstd * (g - dbeta / P - xhat * dgamma / P);  dres = g (returned in place of dy when res was used)
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const bf16_raw *__restrict__ x, const bf16_raw *__restrict__ y,
+                                                             const bf16_raw *__restrict__ dy, int cs, size_t P, int C,
+                                                             const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
+                                                             double *__restrict__ partial)
+{
+    const int C8 = C / 8, g = threadIdx.x % C8, pl = threadIdx.x / C8, npl = 256 / C8;
+    double s[8] = {}, q[8] = {};
+    if (pl < npl)
+        for (size_t p = (size_t)blockIdx.x * npl + pl; p < P; p += (size_t)gridDim.x * npl) {
+            const uint4 xv = *reinterpret_cast<const uint4 *>(x + p * cs + g * 8);
+            const uint4 yv = *reinterpret_cast<const uint4 *>(y + p * cs + g * 8);
+            const uint4 dv = *reinterpret_cast<const uint4 *>(dy + p * cs + g * 8);
+            const unsigned xu[4] = {xv.x, xv.y, xv.z, xv.w}, yu[4] = {yv.x, yv.y, yv.z, yv.w}, du[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = g * 8 + 2 * k + h;
+                    const float xf = __builtin_bit_cast(float, h ? (xu[k] & 0xffff0000u) : (xu[k] << 16));
+                    const float yf = __builtin_bit_cast(float, h ? (yu[k] & 0xffff0000u) : (yu[k] << 16));
+                    float gf = __builtin_bit_cast(float, h ? (du[k] & 0xffff0000u) : (du[k] << 16));
+                    if (relu && !(yf > 0.f)) gf = 0.f;
+                    s[2 * k + h] += gf;
+                    q[2 * k + h] += (double)gf * ((xf - mean[c]) * invstd[c]);
+                }
+        }
+    __shared__ double sh[2][256][8 + 1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sh[0][threadIdx.x][i] = s[i]; sh[1][threadIdx.x][i] = q[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int gg = c / 8, i = c % 8;
+        double a = 0, b = 0;
+        for (int l = 0; l < npl; ++l) { a += sh[0][l * C8 + gg][i]; b += sh[1][l * C8 + gg][i]; }
+        partial[((size_t)blockIdx.x * C + c) * 2] = a;
+        partial[((size_t)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+}
+__global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblocks, int C, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int i = 0; i < nblocks; ++i) { a += partial[((size_t)i * C + c) * 2]; b += partial[((size_t)i * C + c) * 2 + 1]; }
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)b;
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_raw *__restrict__ x, const bf16_raw *__restrict__ y,
+                                                           const bf16_raw *__restrict__ dy, int cs, size_t P, int C,
+                                                           const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                           const float *__restrict__ gamma, const float *__restrict__ dgamma,
+                                                           const float *__restrict__ dbeta, int relu, bf16_raw *__restrict__ dx,
+                                                           bf16_raw *__restrict__ dres)
+{
+    const int C8 = C / 8;
+    const size_t total = P * C8;
+    const float invP = (float)(1.0 / (double)P);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t p = i / C8;
+        const int g = (int)(i % C8);
+        const uint4 xv = *reinterpret_cast<const uint4 *>(x + p * cs + g * 8);
+        const uint4 yv = *reinterpret_cast<const uint4 *>(y + p * cs + g * 8);
+        const uint4 dv = *reinterpret_cast<const uint4 *>(dy + p * cs + g * 8);
+        const unsigned xu[4] = {xv.x, xv.y, xv.z, xv.w}, yu[4] = {yv.x, yv.y, yv.z, yv.w}, du[4] = {dv.x, dv.y, dv.z, dv.w};
+        unsigned o[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float out[2], gr[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = g * 8 + 2 * k + h;
+                const float xf = __builtin_bit_cast(float, h ? (xu[k] & 0xffff0000u) : (xu[k] << 16));
+                const float yf = __builtin_bit_cast(float, h ? (yu[k] & 0xffff0000u) : (yu[k] << 16));
+                float gf = __builtin_bit_cast(float, h ? (du[k] & 0xffff0000u) : (du[k] << 16));
+                if (relu && !(yf > 0.f)) gf = 0.f;
+                const float xh = (xf - mean[c]) * invstd[c];
+                out[h] = gamma[c] * invstd[c] * (gf - dbeta[c] * invP - xh * dgamma[c] * invP);
+                gr[h] = gf;
+            }
+            o[k] = (unsigned)f2bf_dev(out[0]) | ((unsigned)f2bf_dev(out[1]) << 16);
+            r[k] = (unsigned)f2bf_dev(gr[0]) | ((unsigned)f2bf_dev(gr[1]) << 16);
+        }
+        *reinterpret_cast<uint4 *>(dx + p * cs + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (dres) *reinterpret_cast<uint4 *>(dres + p * cs + g * 8) = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+hipError_t launch_bn_train_backward(const bf16_raw *x, const bf16_raw *y, const bf16_raw *dy, int cs, size_t P, int C, const float *mean,
+                                    const float *invstd, const float *gamma, int relu, bf16_raw *dx, bf16_raw *dres, float *dgamma,
+                                    float *dbeta, double *scratch, hipStream_t s)
+{
+    const int nblocks = HH_BN_BLOCKS;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblocks), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, relu, scratch);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, nblocks, C, dgamma, dbeta);
+    unsigned grid = (unsigned)((P * (C / 8) + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, dgamma, dbeta, relu, dx, dres);
+    return hipGetLastError();
+}

@@ -1,0 +1,84 @@
+"""Python face of the training building blocks (`hh_conv2d`, `hh_bn_train_*`): NHWC bf16 activations as torch tensors
+in channels_last memory format, fp32 parameters.  Not yet assembled into a trainable net."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from .. import _lib
+
+
+def _nhwc(x: Tensor) -> Tensor:
+    """[B,C,H,W] bf16 tensor whose memory is NHWC (channels_last); returns it contiguous in that format."""
+    if not x.is_cuda or x.dtype != torch.bfloat16 or x.dim() != 4:
+        raise _lib.HHError("expected a 4-d CUDA/HIP bfloat16 tensor: there is no CPU path")
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def conv2d(x: Tensor, w: Tensor, stride: int = 1, bias: Tensor | None = None, res: Tensor | None = None, relu: bool = False,
+           data_grad: bool = False) -> Tensor:
+    """y = act(conv(x, w) + bias (+ res)), padding (ks-1)/2.  data_grad=True: x is dL/dy of the stride-1 conv with weights
+    w [cout,cin,ks,ks] and the result is dL/dx."""
+    lib = _lib.load()
+    x = _nhwc(x)
+    B, Cx, H, W = x.shape
+    cout, cin, ks, _ = w.shape
+    w = w.detach().to(x.device, torch.float32).contiguous()
+    if Cx != (cout if data_grad else cin):
+        raise ValueError(f"conv2d: input has {Cx} channels, weights {tuple(w.shape)}, data_grad={data_grad}")
+    co = cin if data_grad else cout
+    Ho, Wo = (H // 2, W // 2) if stride == 2 else (H, W)
+    y = torch.empty((B, co, Ho, Wo), device=x.device, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    nbytes = lib.hh_conv2d_workspace_bytes(cin, cout, ks, int(data_grad))
+    if nbytes < 0:
+        raise _lib.HHError("conv2d: no kernel family for this shape")
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    if res is not None:
+        res = _nhwc(res)
+    if bias is not None:
+        bias = bias.detach().to(x.device, torch.float32).contiguous()
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    with torch.cuda.device(x.device):
+        _lib.check(lib.hh_conv2d(x.data_ptr(), B, H, W, cin, w.data_ptr(), cout, ks, stride, int(data_grad),
+                                 bias.data_ptr() if bias is not None else None, res.data_ptr() if res is not None else None,
+                                 int(relu), y.data_ptr(), ws.data_ptr(), stream))
+    return y
+
+
+def bn_train_forward(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, res: Tensor | None = None, relu: bool = False):
+    """-> (y, mean, invstd): BatchNorm2d in training mode (+ residual, + ReLU); mean / invstd feed the backward."""
+    lib = _lib.load()
+    x = _nhwc(x)
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+    scratch = torch.empty(256 * C * 2, device=x.device, dtype=torch.float64)
+    if res is not None:
+        res = _nhwc(res)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    with torch.cuda.device(x.device):
+        _lib.check(lib.hh_bn_train_forward(x.data_ptr(), B * H * W, C, gamma.float().contiguous().data_ptr(), beta.float().contiguous().data_ptr(),
+                                           eps, res.data_ptr() if res is not None else None, int(relu), y.data_ptr(), mean.data_ptr(),
+                                           invstd.data_ptr(), scratch.data_ptr(), stream))
+    return y, mean, invstd
+
+
+def bn_train_backward(x: Tensor, y: Tensor, dy: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, relu: bool = False,
+                      want_dres: bool = False):
+    """-> (dx, dgamma, dbeta, dres or None)"""
+    lib = _lib.load()
+    x, y, dy = _nhwc(x), _nhwc(y), _nhwc(dy)
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+    scratch = torch.empty(256 * C * 2, device=x.device, dtype=torch.float64)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    g = gamma.float().contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.hh_bn_train_backward(x.data_ptr(), y.data_ptr(), dy.data_ptr(), B * H * W, C, mean.data_ptr(), invstd.data_ptr(),
+                                            g.data_ptr(), int(relu), dx.data_ptr(), dres.data_ptr() if dres is not None else None,
+                                            dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(), stream))
+    return dx, dgamma, dbeta, dres

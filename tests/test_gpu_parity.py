@@ -430,3 +430,60 @@ def test_full_size_properties_batch32_512(pkg):
     # the oracle agrees on one of the full-size images (takes ~0.3 s per image)
     rj, rs = orc.decode(uniq[0][0], uniq[0][1], [uniq[0][2][0]], max_people=30, det_thr=0.05, tag_thr=0.5)
     assert np.array_equal(j[0, : n[0]], rj) and np.array_equal(scores[0, : n[0]].cpu().numpy(), rs)
+
+
+def _bf(t):  # round to bf16 and back: the values the kernels actually see
+    return t.to(torch.bfloat16).float()
+
+
+def test_training_building_blocks_conv_and_batchnorm(pkg):
+    """hh_conv2d (forward with the current fp32 weights, stride 1/2, 1x1/3x3, and the stride-1 data gradient) and train-mode
+    BatchNorm forward/backward against torch fp32 on the same bf16-rounded operands.  Tolerance: bf16 output rounding
+    (2^-8 relative) plus fp32 accumulation order -> 1.5 % of the tensor's max."""
+    ops = importlib.import_module(PKG + ".keypoints.train_ops")
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(0)
+
+    def close(got, ref, what, tol=1.5e-2):
+        got, ref = got.float().cpu(), ref.float()
+        err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+        assert err < tol, (what, err)
+
+    for (cin, cout, ks, stride, hw) in [(64, 64, 3, 1, 32), (32, 32, 3, 1, 40), (128, 64, 1, 1, 16), (64, 256, 1, 1, 24), (64, 128, 3, 2, 32),
+                                        (48, 48, 3, 1, 16), (256, 256, 3, 1, 16)]:
+        x = _bf(torch.randn(2, cin, hw, hw, generator=g))
+        w = _bf(torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5)
+        b = torch.randn(cout, generator=g)
+        res = _bf(torch.randn(2, cout, hw // stride, hw // stride, generator=g))
+        ref = F.relu(F.conv2d(x, w, b, stride, (ks - 1) // 2) + res)
+        got = ops.conv2d(x.to(DEV, torch.bfloat16), w.to(DEV), stride, bias=b.to(DEV), res=res.to(DEV, torch.bfloat16), relu=True)
+        assert got.shape == ref.shape
+        close(got, ref, ("conv", cin, cout, ks, stride))
+        if stride == 1:  # data gradient = autograd of the same conv
+            xr = x.clone().requires_grad_()
+            dy = _bf(torch.randn(2, cout, hw, hw, generator=g))
+            F.conv2d(xr, w, None, 1, (ks - 1) // 2).backward(dy)
+            close(ops.conv2d(dy.to(DEV, torch.bfloat16), w.to(DEV), 1, data_grad=True), xr.grad, ("dgrad", cin, cout, ks))
+    for (C, hw, relu, with_res) in [(32, 24, True, False), (64, 16, True, True), (256, 8, False, False), (48, 12, True, True), (384, 8, True, False)]:
+        x = _bf(torch.randn(3, C, hw, hw, generator=g) * 2 + 0.5).requires_grad_()
+        gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+        gamma.requires_grad_(); beta.requires_grad_()
+        res = _bf(torch.randn(3, C, hw, hw, generator=g)).requires_grad_() if with_res else None
+        z = F.batch_norm(x, None, None, gamma, beta, True, 0.0, 1e-5)
+        ref = z + res if with_res else z
+        ref = F.relu(ref) if relu else ref
+        y, mean, invstd = ops.bn_train_forward(x.detach().to(DEV, torch.bfloat16), gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5,
+                                               res.detach().to(DEV, torch.bfloat16) if with_res else None, relu)
+        close(y, ref.detach(), ("bn fwd", C))
+        np.testing.assert_allclose(mean.cpu().numpy(), x.detach().mean((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(invstd.cpu().numpy(), (x.detach().var((0, 2, 3), unbiased=False) + 1e-5).rsqrt().numpy(), rtol=1e-4)
+        dy = _bf(torch.randn(3, C, hw, hw, generator=g))
+        # reference backward from the SAME rounded forward output the kernel saw (its ReLU mask is y > 0 on the bf16 y)
+        ref.backward(dy)
+        dx, dgamma, dbeta, dres = ops.bn_train_backward(x.detach().to(DEV, torch.bfloat16), y, dy.to(DEV, torch.bfloat16), mean, invstd,
+                                                        gamma.detach().to(DEV), relu, want_dres=with_res)
+        close(dx, x.grad, ("bn dx", C), 2e-2)
+        close(dgamma, gamma.grad, ("bn dgamma", C), 2e-2)
+        close(dbeta, beta.grad, ("bn dbeta", C), 2e-2)
+        if with_res:
+            close(dres, res.grad, ("bn dres", C), 2e-2)
