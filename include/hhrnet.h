@@ -177,8 +177,14 @@ int hh_loss_ae_grouping(const float *tags, int64_t tags_bstride, const int32_t *
  * hh_bn_train_forward = nn.BatchNorm2d in training mode on [P = B*H*W, C] (+ residual, + ReLU): batch mean and biased
  *   variance, y = act(gamma * (x - mean) * invstd + beta (+ res)); mean / invstd are kept for the backward.
  *   scratch: 256 * C * 2 doubles.  (The running statistics are updated by the caller: plain torch arithmetic on C floats.)
- * hh_bn_train_backward: dx, dgamma, dbeta (and dres = the gradient after the ReLU mask, if dres != NULL).               */
+ * hh_bn_train_backward: dx, dgamma, dbeta (and dres = the gradient after the ReLU mask, if dres != NULL).
+ * hh_conv2d_wgrad: dw [cout][cin][ks][ks] fp32 = dL/dW of y = conv(x, W) (padding (ks-1)/2) from x [B,H,W,cin] and
+ *   dy [B,Ho,Wo,cout]; 3x3 stride 1/2 and 1x1 stride 1, channel counts % 8 == 0.  A GEMM contracted over pixels on MFMA
+ *   (operands read from LDS with the transposing ds_read_b64_tr_b16), partial sums reduced in a fixed order.          */
 int64_t hh_conv2d_workspace_bytes(int cin, int cout, int ks, int mode);
+int64_t hh_conv2d_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int ks, int stride);
+int hh_conv2d_wgrad(const void *x, const void *dy, int B, int H, int W, int cin, int cout, int ks, int stride, float *dw, void *workspace,
+                    void *stream);
 int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int cout, int ks, int stride, int mode, const float *bias,
               const void *res, int relu, void *y, void *workspace, void *stream);
 int hh_bn_train_forward(const void *x, int64_t P, int C, const float *gamma, const float *beta, float eps, const void *res, int relu,

@@ -211,6 +211,25 @@ int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int c
     return 0;
 }
 
+int64_t hh_conv2d_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int ks, int stride)
+{
+    const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
+    return (int64_t)conv_wgrad_num_workers(B, Ho, Wo, stride) * ks * ks * round_up_i(cout, 64) * round_up_i(cin, 64) * 4;
+}
+
+int hh_conv2d_wgrad(const void *x, const void *dy, int B, int H, int W, int cin, int cout, int ks, int stride, float *dw, void *workspace,
+                    void *stream)
+{
+    if (!x || !dy || !dw || !workspace || B <= 0 || H <= 0 || W <= 0) { hh_set_error("hh_conv2d_wgrad: bad argument"); return 1; }
+    if (cin % 8 || cout % 8) { hh_set_error("hh_conv2d_wgrad: channel counts must be multiples of 8"); return 1; }
+    if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1))) { hh_set_error("hh_conv2d_wgrad: 3x3 (stride 1 or 2) and 1x1 (stride 1) only"); return 1; }
+    WgradParams p{};
+    p.x = (const bf16_raw *)x; p.dy = (const bf16_raw *)dy; p.partial = (float *)workspace;
+    p.B = B; p.H = H; p.W = W; p.Ho = stride == 2 ? H / 2 : H; p.Wo = stride == 2 ? W / 2 : W; p.cin = cin; p.cout = cout;
+    HH_CHECK_HIP(conv_wgrad_launch(p, ks, stride, dw, (hipStream_t)stream));
+    return 0;
+}
+
 int hh_bn_train_forward(const void *x, int64_t P, int C, const float *gamma, const float *beta, float eps, const void *res, int relu,
                         void *y, float *mean, float *invstd, double *scratch, void *stream)
 {

@@ -1,0 +1,179 @@
+// Weight gradient of a convolution on NHWC bf16 activations (training path):
+//   dW[co][ci][ky][kx] = sum over (b, y, x) of dY[b, y, x, co] * X[b, y*S + ky - pad, x*S + kx - pad, ci]   (zero padded)
+// As MFMA work this is a GEMM whose contraction runs over PIXELS: per tap, D[co][ci] += A[co][16 px] * B[16 px][ci].
+// Both operands therefore need 8 consecutive pixels of ONE channel per lane, while NHWC keeps the channels of one pixel
+// together -- the tiles are staged row-major ([pixel][channel], exactly as they come from HBM) and read back with
+// gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block and each lane
+// receives one column), so no separate transpose pass exists.
+// One workgroup = 4 waves = the 2x2 (co, ci) tiles of 32 of one 64x64 channel block; every wave keeps KS*KS accumulators
+// (one per tap) and the workgroup walks pixel tiles persistently; partial sums go to a workspace that a second kernel
+// reduces in a fixed order (deterministic, no atomics).
+#include "kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int RS = 144;  // LDS bytes per staged pixel: 64 channels + 16 pad
+constexpr int TH = 4;
+
+template <typename F, int... I>
+__device__ __forceinline__ void sfor_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F &&f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+__device__ __forceinline__ i16x4 tr_read(const char *lds, int byte_off)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4 *)(lds + byte_off));
+}
+}  // namespace
+
+template <int KS, int S, int TW>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
+{
+    constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, NTAP = KS * KS;
+    constexpr int Y_UNITS = TH * TW * 8, X_UNITS = PH * PW * 8;          // 16-byte units (8 per 64-channel pixel)
+    constexpr int NYL = (Y_UNITS + 255) / 256, NXL = (X_UNITS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *ldsY = smem, *ldsX = smem + TH * TW * RS;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tco = wave >> 1, tci = wave & 1;
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, hh = g >> 1;
+    const int ncib = (p.cin + 63) / 64;
+    const int co0 = (blockIdx.y / ncib) * 64, ci0 = (blockIdx.y % ncib) * 64;  // channel block of this workgroup
+    const int pad = (KS - 1) / 2;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH, ntiles = p.B * tiles_y * tiles_x;
+
+    f32x16 acc[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // byte offsets of this lane's transposed reads inside a tile (row part added per k-step)
+    const int ycol = (tco * 32 + 16 * (g & 1) + 4 * pp) * 2, xcol = (tci * 32 + 16 * (g & 1) + 4 * pp) * 2;
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int r = t;
+        const int tx = r % tiles_x; r /= tiles_x;
+        const int ty = r % tiles_y;
+        const int b = r / tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
+        // ---- stage dY tile and X patch: [pixel][64 channels], zero outside the image / beyond the channel count
+        u32x4 yreg[NYL], xreg[NXL];
+        sfor<NYL>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int u = tid + 256 * i, px = u >> 3, part = u & 7;
+            const int oy = oy0 + px / TW, ox = ox0 + px % TW, c = co0 + part * 8;
+            const bool ok = (u < Y_UNITS) & (oy < p.Ho) & (ox < p.Wo) & (c < p.cout);
+            const size_t off = ok ? (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.cout + c : 0;
+            yreg[i] = *reinterpret_cast<const u32x4 *>(p.dy + off);
+            if (!ok) yreg[i] = u32x4{0u, 0u, 0u, 0u};
+        });
+        sfor<NXL>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int u = tid + 256 * i, px = u >> 3, part = u & 7;
+            const int iy = iy0 + px / PW, ix = ix0 + px % PW, c = ci0 + part * 8;
+            const bool ok = (u < X_UNITS) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W) & (c < p.cin);
+            const size_t off = ok ? (((size_t)b * p.H + iy) * p.W + ix) * p.cin + c : 0;
+            xreg[i] = *reinterpret_cast<const u32x4 *>(p.x + off);
+            if (!ok) xreg[i] = u32x4{0u, 0u, 0u, 0u};
+        });
+        __syncthreads();  // the previous tile's reads are done
+        sfor<NYL>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int u = tid + 256 * i;
+            if (u < Y_UNITS) *reinterpret_cast<u32x4 *>(ldsY + (u >> 3) * RS + (u & 7) * 16) = yreg[i];
+        });
+        sfor<NXL>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int u = tid + 256 * i;
+            if (u < X_UNITS) *reinterpret_cast<u32x4 *>(ldsX + (u >> 3) * RS + (u & 7) * 16) = xreg[i];
+        });
+        __syncthreads();
+        // ---- contraction over the tile's pixels, 16 per MFMA k-step (one half row of TW = 32, or a row of TW = 16)
+#pragma unroll
+        for (int y = 0; y < TH; ++y)
+#pragma unroll
+            for (int hx = 0; hx < TW / 16; ++hx) {
+                const int prow = y * TW + hx * 16 + 8 * hh + q;  // dY pixel row of this lane's first transposed read
+                const i16x4 a0 = tr_read(ldsY, prow * RS + ycol), a1 = tr_read(ldsY, (prow + 4) * RS + ycol);
+                const i16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                sfor<NTAP>([&](auto tc) {
+                    constexpr int tap = decltype(tc)::value, ky = tap / KS, kx = tap % KS;
+                    const int xrow = (y * S + ky) * PW + (hx * 16 + 8 * hh + q) * S + kx;
+                    const i16x4 b0 = tr_read(ldsX, xrow * RS + xcol), b1 = tr_read(ldsX, (xrow + 4 * S) * RS + xcol);
+                    const i16x8 bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb), acc[tap], 0, 0, 0);
+                });
+            }
+    }
+    // ---- partial sums of this workgroup: part[blockIdx.x][tap][coutp][cinp], D layout: lane = ci column, regs = co rows
+    const int r32 = lane & 31, h = lane >> 5;
+    const int coutp = (p.cout + 63) / 64 * 64, cinp = ncib * 64;
+    float *part = p.partial + (size_t)blockIdx.x * NTAP * coutp * cinp;
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + tco * 32 + 8 * gg + 4 * h + i, ci = ci0 + tci * 32 + r32;
+                part[((size_t)tap * coutp + co) * cinp + ci] = acc[tap][4 * gg + i];
+            }
+}
+
+// dW[co][ci][tap] = sum over workgroups (fixed order) of part[wg][tap][co][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int nwg, int ntap, int cout, int cin, int coutp,
+                                                           int cinp, float *__restrict__ dw)
+{
+    const size_t total = (size_t)cout * cin * ntap;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int tap = (int)(i % ntap);
+        const int ci = (int)((i / ntap) % cin), co = (int)(i / ntap / cin);
+        const size_t o = ((size_t)tap * coutp + co) * cinp + ci, stride = (size_t)ntap * coutp * cinp;
+        float s = 0.f;
+        for (int w = 0; w < nwg; ++w) s += part[(size_t)w * stride + o];
+        dw[i] = s;
+    }
+}
+
+template <int KS, int S, int TW>
+static hipError_t launch_one(const WgradParams &p, int nwg, hipStream_t s)
+{
+    constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
+    const size_t lds = (size_t)(TH * TW + PH * PW) * RS;
+    auto fn = conv_wgrad_kernel<KS, S, TW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int ncob = (p.cout + 63) / 64, ncib = (p.cin + 63) / 64;
+    hipLaunchKernelGGL(fn, dim3(nwg, ncob * ncib), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+int conv_wgrad_num_workers(int B, int Ho, int Wo, int stride)
+{
+    const int TW = stride == 2 ? 16 : 32;
+    const int ntiles = B * ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW);
+    return ntiles < HH_WGRAD_WORKERS ? ntiles : HH_WGRAD_WORKERS;
+}
+
+hipError_t conv_wgrad_launch(const WgradParams &p, int ks, int stride, float *dw, hipStream_t s)
+{
+    const int nwg = conv_wgrad_num_workers(p.B, p.Ho, p.Wo, stride);
+    hipError_t e = hipErrorInvalidValue;
+    if (ks == 3 && stride == 1) e = launch_one<3, 1, 32>(p, nwg, s);
+    else if (ks == 1 && stride == 1) e = launch_one<1, 1, 32>(p, nwg, s);
+    else if (ks == 3 && stride == 2) e = launch_one<3, 2, 16>(p, nwg, s);
+    if (e != hipSuccess) return e;
+    const int coutp = (p.cout + 63) / 64 * 64, cinp = (p.cin + 63) / 64 * 64, ntap = ks * ks;
+    const size_t total = (size_t)p.cout * p.cin * ntap;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, p.partial, nwg, ntap, p.cout, p.cin, coutp, cinp, dw);
+    return hipGetLastError();
+}

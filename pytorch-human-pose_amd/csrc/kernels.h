@@ -140,3 +140,14 @@ hipError_t launch_bn_train_forward(const bf16_raw *x, int cs, size_t P, int C, c
 hipError_t launch_bn_train_backward(const bf16_raw *x, const bf16_raw *y, const bf16_raw *dy, int cs, size_t P, int C, const float *mean,
                                     const float *invstd, const float *gamma, int relu, bf16_raw *dx, bf16_raw *dres, float *dgamma,
                                     float *dbeta, double *scratch, hipStream_t s);
+
+// Convolution weight gradient (conv_wgrad.hip): ks in {1,3} x stride 1, and 3x3 stride 2; channels multiples of 8
+struct WgradParams {
+    const bf16_raw *x;   // [B,H,W,cin]
+    const bf16_raw *dy;  // [B,Ho,Wo,cout]
+    float *partial;      // workspace: workers * ks*ks * roundup(cout,64) * roundup(cin,64) floats
+    int B, H, W, Ho, Wo, cin, cout;
+};
+#define HH_WGRAD_WORKERS 128  // persistent pixel-tile workers per channel block
+int conv_wgrad_num_workers(int B, int Ho, int Wo, int stride);
+hipError_t conv_wgrad_launch(const WgradParams &p, int ks, int stride, float *dw, hipStream_t s);

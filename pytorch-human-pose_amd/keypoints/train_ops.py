@@ -82,3 +82,17 @@ def bn_train_backward(x: Tensor, y: Tensor, dy: Tensor, mean: Tensor, invstd: Te
                                             g.data_ptr(), int(relu), dx.data_ptr(), dres.data_ptr() if dres is not None else None,
                                             dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(), stream))
     return dx, dgamma, dbeta, dres
+
+
+def conv2d_weight_grad(x: Tensor, dy: Tensor, ks: int, stride: int = 1) -> Tensor:
+    """dL/dW [cout,cin,ks,ks] fp32 of y = conv(x, W) (padding (ks-1)/2) from the layer input x and dL/dy."""
+    lib = _lib.load()
+    x, dy = _nhwc(x), _nhwc(dy)
+    B, cin, H, W = x.shape
+    cout = dy.shape[1]
+    dw = torch.empty((cout, cin, ks, ks), device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.hh_conv2d_wgrad_workspace_bytes(B, H, W, cin, cout, ks, stride), device=x.device, dtype=torch.uint8)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    with torch.cuda.device(x.device):
+        _lib.check(lib.hh_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), B, H, W, cin, cout, ks, stride, dw.data_ptr(), ws.data_ptr(), stream))
+    return dw

@@ -459,10 +459,12 @@ def test_training_building_blocks_conv_and_batchnorm(pkg):
         got = ops.conv2d(x.to(DEV, torch.bfloat16), w.to(DEV), stride, bias=b.to(DEV), res=res.to(DEV, torch.bfloat16), relu=True)
         assert got.shape == ref.shape
         close(got, ref, ("conv", cin, cout, ks, stride))
-        if stride == 1:  # data gradient = autograd of the same conv
-            xr = x.clone().requires_grad_()
-            dy = _bf(torch.randn(2, cout, hw, hw, generator=g))
-            F.conv2d(xr, w, None, 1, (ks - 1) // 2).backward(dy)
+        # gradients = torch autograd of the same conv on the same bf16-rounded operands
+        xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+        dy = _bf(torch.randn(2, cout, hw // stride, hw // stride, generator=g))
+        F.conv2d(xr, wr, None, stride, (ks - 1) // 2).backward(dy)
+        close(ops.conv2d_weight_grad(x.to(DEV, torch.bfloat16), dy.to(DEV, torch.bfloat16), ks, stride), wr.grad, ("wgrad", cin, cout, ks, stride), 5e-3)
+        if stride == 1:
             close(ops.conv2d(dy.to(DEV, torch.bfloat16), w.to(DEV), 1, data_grad=True), xr.grad, ("dgrad", cin, cout, ks))
     for (C, hw, relu, with_res) in [(32, 24, True, False), (64, 16, True, True), (256, 8, False, False), (48, 12, True, True), (384, 8, True, False)]:
         x = _bf(torch.randn(3, C, hw, hw, generator=g) * 2 + 0.5).requires_grad_()
