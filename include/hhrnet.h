@@ -173,6 +173,8 @@ int hh_loss_ae_grouping(const float *tags, int64_t tags_bstride, const int32_t *
  * hh_conv2d: y = act(conv(x, w) + bias (+ res)) with the CURRENT fp32 weights w [cout][cin][ks][ks] (packed on the device
  *   each call), ks in {1,3}, stride in {1,2}, padding (ks-1)/2.  mode 1 = data gradient of the stride-1 conv with these
  *   weights: x is dL/dy [B,H,W,cout], y is dL/dx [B,H,W,cin] (the same kernel with rotated, transposed weights).
+ *   mode 2 = data gradient of the 3x3 stride-2 conv: x is dL/dy [B,H,W,cout], y is dL/dx [B,2H,2W,cin] (four
+ *   output-parity phases, each a 2x2 conv over dL/dy).
  *   Input channels (of the conv that runs) % 16 == 0, output channels % 8 == 0; workspace: hh_conv2d_workspace_bytes.
  * hh_bn_train_forward = nn.BatchNorm2d in training mode on [P = B*H*W, C] (+ residual, + ReLU): batch mean and biased
  *   variance, y = act(gamma * (x - mean) * invstd + beta (+ res)); mean / invstd are kept for the backward.

@@ -169,9 +169,9 @@ int64_t hh_conv2d_workspace_bytes(int cin, int cout, int ks, int mode)
     const int ci = mode ? cout : cin, co = mode ? cin : cout;
     const int coutp = round_up_i(co, 32);
     int KC = 0, NT = 0;
-    if (hh_family_pick(ks, 1, round_up_i(ci, 16), coutp, &KC, &NT)) return -1;
+    if (hh_family_pick(mode == 2 ? 2 : ks, 1, round_up_i(ci, 16), coutp, &KC, &NT)) return -1;
     const int cin_pad = round_up_i(ci, KC);
-    return (int64_t)coutp * cin_pad * ks * ks * 2 + (int64_t)coutp * 4 + 256;
+    return (int64_t)coutp * cin_pad * ks * ks * 2 + (int64_t)coutp * 4 + 512;
 }
 
 int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int cout, int ks, int stride, int mode, const float *bias,
@@ -182,20 +182,21 @@ int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int c
     const int ci = mode ? cout : cin, co = mode ? cin : cout;  // channels of the conv that actually runs
     if (!x || !w || !y || !workspace || B <= 0 || H <= 0 || W <= 0) { hh_set_error("hh_conv2d: bad argument"); return 1; }
     if (ci % 16 || co % 8) { hh_set_error("hh_conv2d: input channels must be a multiple of 16 and output channels of 8"); return 1; }
-    if (mode && stride != 1) { hh_set_error("hh_conv2d: the data-gradient mode covers stride-1 convolutions"); return 1; }
+    if (mode == 1 && stride != 1) { hh_set_error("hh_conv2d: mode 1 is the data gradient of a stride-1 convolution"); return 1; }
+    if (mode == 2 && (stride != 2 || ks != 3)) { hh_set_error("hh_conv2d: mode 2 is the data gradient of a 3x3 stride-2 convolution"); return 1; }
     const int coutp = round_up_i(co, 32);
+    const int kks = mode == 2 ? 2 : ks, kstride = mode == 2 ? 1 : stride;  // kernel that actually runs
     int KC = 0, NT = 0;
-    if (hh_family_pick(ks, stride, ci, coutp, &KC, &NT)) { hh_set_error("hh_conv2d: no kernel family for this shape"); return 1; }
+    if (hh_family_pick(kks, kstride, ci, coutp, &KC, &NT)) { hh_set_error("hh_conv2d: no kernel family for this shape"); return 1; }
     const int COUT_T = 32 * NT, cin_pad = round_up_i(ci, KC);
-    const size_t wel = (size_t)coutp * cin_pad * ks * ks;
+    const size_t wel = (size_t)coutp * cin_pad * kks * kks;
     bf16_raw *packed = (bf16_raw *)workspace;
     float *zbias = (float *)((char *)workspace + ((wel * 2 + 255) & ~(size_t)255));
     hipStream_t s = (hipStream_t)stream;
-    HH_CHECK_HIP(launch_pack_weights(w, cout, cin, ks, mode, KC, COUT_T, packed, wel, s));
     if (bias) HH_CHECK_HIP(hipMemcpyAsync(zbias, bias, (size_t)co * 4, hipMemcpyDeviceToDevice, s));
     else HH_CHECK_HIP(hipMemsetAsync(zbias, 0, (size_t)coutp * 4, s));
-    const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
-    const int cfg = hh_pick_config(ks, stride, KC, NT, Wo);
+    const int Ho = kstride == 2 ? H / 2 : H, Wo = kstride == 2 ? W / 2 : W;
+    const int cfg = hh_pick_config(kks, kstride, KC, NT, Wo);
     if (cfg < 0) { hh_set_error("hh_conv2d: no kernel instantiation for this shape"); return 1; }
     const ConvConfig &cc = conv_config(cfg);
     ConvParams p{};
@@ -207,6 +208,16 @@ int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int c
     p.cin = cin_pad; p.cout_real = co; p.cout_store = co; p.relu = relu;
     p.pad_y = p.pad_x = (ks - 1) / 2; p.B = B;
     p.tiles_x = (Wo + cc.TW - 1) / cc.TW; p.tiles_y = (Ho + cc.th() - 1) / cc.th(); p.ncg = coutp / cc.cout_t();
+    if (mode == 2) {  // four output-parity phases, each a 2x2 conv over dL/dy scattered onto the 2H x 2W grid
+        p.Hob = 2 * H; p.Wob = 2 * W; p.osy = p.osx = 2; p.pad_y = p.pad_x = 0;
+        for (int ph = 0; ph < 4; ++ph) {
+            HH_CHECK_HIP(launch_pack_weights(w, cout, cin, 2, 2, KC, COUT_T, packed, wel, s, ph >> 1, ph & 1));
+            p.ooy = ph >> 1; p.oox = ph & 1;
+            HH_CHECK_HIP(conv_launch(cfg, p, s));
+        }
+        return 0;
+    }
+    HH_CHECK_HIP(launch_pack_weights(w, cout, cin, ks, mode, KC, COUT_T, packed, wel, s));
     HH_CHECK_HIP(conv_launch(cfg, p, s));
     return 0;
 }

@@ -14,8 +14,11 @@ __device__ __forceinline__ bf16_raw f2bf_dev(float f) { return __builtin_bit_cas
 //   mode 0: conv weights W[cout][cin][ks][ks]                      -> out channel o = co, in channel i = ci, tap (ky,kx)
 //   mode 1: data gradient of a stride-1 conv: the forward conv of dL/dy with W'[ci][co][ks-1-ky][ks-1-kx]
 //           (cout_eff = cin, cin_eff = cout)
+//   mode 2: data gradient of a 3x3 stride-2 conv, one output-parity phase (py, px) as a 2x2 conv over dL/dy:
+//           dX[2i+py, 2j+px] = sum_t W'[t] dY[i + ty, j + tx];  even parity uses the centre tap only (ty = 0 <-> ky = 1),
+//           odd parity ty = 0 <-> ky = 2 and ty = 1 <-> ky = 0 (same in x).  `ks` is then 2 (the packed kernel size).
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ W, int cout, int cin, int ks, int mode, int KC,
-                                                           int COUT_T, bf16_raw *__restrict__ packed, size_t total)
+                                                           int COUT_T, bf16_raw *__restrict__ packed, size_t total, int py, int px)
 {
     const int co_eff = mode ? cin : cout, ci_eff = mode ? cout : cin;
     const int cin_pad = (ci_eff + KC - 1) / KC * KC, nch = cin_pad / KC, taps = ks * ks, C8 = KC / 8;
@@ -29,19 +32,26 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
         const int cg = (int)r;
         const int oc = cg * COUT_T + co_in, ic = ch * KC + c8 * 8 + j, ky = t / ks, kx = t % ks;
         float v = 0.f;
-        if (oc < co_eff && ic < ci_eff)
-            v = mode ? W[(((size_t)ic * cin + oc) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)]   // W[co = ic][ci = oc][rot]
-                     : W[(((size_t)oc * cin + ic) * ks + ky) * ks + kx];
+        if (oc < co_eff && ic < ci_eff) {
+            if (mode == 2) {
+                const int sy = py ? (ky ? 0 : 2) : (ky ? -1 : 1), sx = px ? (kx ? 0 : 2) : (kx ? -1 : 1);  // source tap of the 3x3 kernel
+                if (sy >= 0 && sx >= 0) v = W[(((size_t)ic * cin + oc) * 3 + sy) * 3 + sx];
+            } else if (mode == 1) {
+                v = W[(((size_t)ic * cin + oc) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];  // W[co = ic][ci = oc][rot]
+            } else {
+                v = W[(((size_t)oc * cin + ic) * ks + ky) * ks + kx];
+            }
+        }
         packed[o] = f2bf_dev(v);
     }
 }
 
 hipError_t launch_pack_weights(const float *W, int cout, int cin, int ks, int mode, int KC, int COUT_T, bf16_raw *packed, size_t total,
-                               hipStream_t s)
+                               hipStream_t s, int py, int px)
 {
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, s, W, cout, cin, ks, mode, KC, COUT_T, packed, total);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, s, W, cout, cin, ks, mode, KC, COUT_T, packed, total, py, px);
     return hipGetLastError();
 }
 

@@ -17,8 +17,8 @@ def _nhwc(x: Tensor) -> Tensor:
 
 def conv2d(x: Tensor, w: Tensor, stride: int = 1, bias: Tensor | None = None, res: Tensor | None = None, relu: bool = False,
            data_grad: bool = False) -> Tensor:
-    """y = act(conv(x, w) + bias (+ res)), padding (ks-1)/2.  data_grad=True: x is dL/dy of the stride-1 conv with weights
-    w [cout,cin,ks,ks] and the result is dL/dx."""
+    """y = act(conv(x, w) + bias (+ res)), padding (ks-1)/2.  data_grad=True: x is dL/dy of the conv with weights
+    w [cout,cin,ks,ks] and this stride, and the result is dL/dx (stride 2: 3x3 only, even input sizes)."""
     lib = _lib.load()
     x = _nhwc(x)
     B, Cx, H, W = x.shape
@@ -27,9 +27,13 @@ def conv2d(x: Tensor, w: Tensor, stride: int = 1, bias: Tensor | None = None, re
     if Cx != (cout if data_grad else cin):
         raise ValueError(f"conv2d: input has {Cx} channels, weights {tuple(w.shape)}, data_grad={data_grad}")
     co = cin if data_grad else cout
-    Ho, Wo = (H // 2, W // 2) if stride == 2 else (H, W)
+    mode = (2 if stride == 2 else 1) if data_grad else 0
+    if mode == 2:
+        Ho, Wo = 2 * H, 2 * W  # dL/dx of a stride-2 conv lives on the input grid
+    else:
+        Ho, Wo = (H // 2, W // 2) if stride == 2 else (H, W)
     y = torch.empty((B, co, Ho, Wo), device=x.device, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    nbytes = lib.hh_conv2d_workspace_bytes(cin, cout, ks, int(data_grad))
+    nbytes = lib.hh_conv2d_workspace_bytes(cin, cout, ks, mode)
     if nbytes < 0:
         raise _lib.HHError("conv2d: no kernel family for this shape")
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
@@ -39,7 +43,7 @@ def conv2d(x: Tensor, w: Tensor, stride: int = 1, bias: Tensor | None = None, re
         bias = bias.detach().to(x.device, torch.float32).contiguous()
     stream = torch.cuda.current_stream(x.device).cuda_stream
     with torch.cuda.device(x.device):
-        _lib.check(lib.hh_conv2d(x.data_ptr(), B, H, W, cin, w.data_ptr(), cout, ks, stride, int(data_grad),
+        _lib.check(lib.hh_conv2d(x.data_ptr(), B, H, W, cin, w.data_ptr(), cout, ks, stride, mode,
                                  bias.data_ptr() if bias is not None else None, res.data_ptr() if res is not None else None,
                                  int(relu), y.data_ptr(), ws.data_ptr(), stream))
     return y
