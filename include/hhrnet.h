@@ -171,7 +171,8 @@ int hh_loss_ae_grouping(const float *tags, int64_t tags_bstride, const int32_t *
  * parameters fp32, all device pointers.
  *
  * hh_conv2d: y = act(conv(x, w) + bias (+ res)) with the CURRENT fp32 weights w [cout][cin][ks][ks] (packed on the device
- *   each call), ks in {1,3}, stride in {1,2}, padding (ks-1)/2.  mode 1 = data gradient of the stride-1 conv with these
+ *   each call), ks in {1,2,3} (2x2: stride 1), stride in {1,2}; pad_y / pad_x = top / left zero padding, -1 = (ks-1)/2
+ *   (the output keeps the input size at stride 1, so a 2x2 kernel with pad 0 pads bottom/right instead).  mode 1 = data gradient of the stride-1 conv with these
  *   weights: x is dL/dy [B,H,W,cout], y is dL/dx [B,H,W,cin] (the same kernel with rotated, transposed weights).
  *   mode 2 = data gradient of the 3x3 stride-2 conv: x is dL/dy [B,H,W,cout], y is dL/dx [B,2H,2W,cin] (four
  *   output-parity phases, each a 2x2 conv over dL/dy).
@@ -185,10 +186,10 @@ int hh_loss_ae_grouping(const float *tags, int64_t tags_bstride, const int32_t *
  *   (operands read from LDS with the transposing ds_read_b64_tr_b16), partial sums reduced in a fixed order.          */
 int64_t hh_conv2d_workspace_bytes(int cin, int cout, int ks, int mode);
 int64_t hh_conv2d_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int ks, int stride);
-int hh_conv2d_wgrad(const void *x, const void *dy, int B, int H, int W, int cin, int cout, int ks, int stride, float *dw, void *workspace,
-                    void *stream);
-int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int cout, int ks, int stride, int mode, const float *bias,
-              const void *res, int relu, void *y, void *workspace, void *stream);
+int hh_conv2d_wgrad(const void *x, const void *dy, int B, int H, int W, int cin, int cout, int ks, int stride, int pad_y, int pad_x, float *dw,
+                    void *workspace, void *stream);
+int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int cout, int ks, int stride, int mode, int pad_y, int pad_x,
+              const float *bias, const void *res, int relu, void *y, void *workspace, void *stream);
 int hh_bn_train_forward(const void *x, int64_t P, int C, const float *gamma, const float *beta, float eps, const void *res, int relu,
                         void *y, float *mean, float *invstd, double *scratch, void *stream);
 int hh_bn_train_backward(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd,

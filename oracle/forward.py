@@ -31,7 +31,12 @@ class _SD:
         return self.sd[f"{self.prefix}{name}"]
 
 
+_TRAIN = False  # set by higher_hrnet(..., train=True): BatchNorm normalises with batch statistics (nn.Module.train())
+
+
 def _bn(x, p: _SD):
+    if _TRAIN:  # hrnet.py uses nn.BatchNorm2d defaults: batch statistics, momentum 0.1 (running stats not needed here)
+        return F.batch_norm(x, None, None, p["weight"], p["bias"], True, 0.0, EPS)
     return F.batch_norm(x, p["running_mean"], p["running_var"], p["weight"], p["bias"], False, 0.0, EPS)
 
 
@@ -120,8 +125,17 @@ def backbone(x, p: _SD, single_scale_out: bool = True):
     return xs, taps
 
 
-def higher_hrnet(images: torch.Tensor, sd: dict, num_kpts: int = 17, return_taps: bool = False):
-    """higher_hrnet.py:66-81 -> ([hm_1/4, hm_1/2], tags_1/4)."""
+def higher_hrnet(images: torch.Tensor, sd: dict, num_kpts: int = 17, return_taps: bool = False, train: bool = False):
+    """higher_hrnet.py:66-81 -> ([hm_1/4, hm_1/2], tags_1/4).  train=True: the net in .train() mode (batch-stat BN)."""
+    global _TRAIN
+    _TRAIN = train
+    try:
+        return _higher_hrnet(images, sd, num_kpts, return_taps)
+    finally:
+        _TRAIN = False
+
+
+def _higher_hrnet(images: torch.Tensor, sd: dict, num_kpts: int, return_taps: bool):
     p = _SD(sd)
     K = num_kpts
     xs, taps = backbone(images, p.sub("backbone"), True)

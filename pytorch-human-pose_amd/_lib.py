@@ -72,9 +72,9 @@ def _sig(lib):
         "hh_loss_heatmaps": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, i64, vp, vp]),
         "hh_loss_ae_grouping": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, vp, i64, C.c_float, C.c_float, vp, vp]),
         "hh_conv2d_workspace_bytes": (i64, [i32, i32, i32, i32]),
-        "hh_conv2d": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp]),
+        "hh_conv2d": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp]),
         "hh_conv2d_wgrad_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32, i32]),
-        "hh_conv2d_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+        "hh_conv2d_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
         "hh_bn_train_forward": (i32, [vp, i64, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, vp, vp]),
         "hh_bn_train_backward": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
         "hh_resize_accumulate": (i32, [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, C.c_float, i32, vp]),

@@ -174,15 +174,19 @@ int64_t hh_conv2d_workspace_bytes(int cin, int cout, int ks, int mode)
     return (int64_t)coutp * cin_pad * ks * ks * 2 + (int64_t)coutp * 4 + 512;
 }
 
-int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int cout, int ks, int stride, int mode, const float *bias,
-              const void *res, int relu, void *y, void *workspace, void *stream)
+int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int cout, int ks, int stride, int mode, int pad_y, int pad_x,
+              const float *bias, const void *res, int relu, void *y, void *workspace, void *stream)
 {
+    if (pad_y < 0) pad_y = (ks - 1) / 2;
+    if (pad_x < 0) pad_x = (ks - 1) / 2;
     static bool inited = false;
     if (!inited) { HH_CHECK_HIP(conv_init()); inited = true; }
     const int ci = mode ? cout : cin, co = mode ? cin : cout;  // channels of the conv that actually runs
     if (!x || !w || !y || !workspace || B <= 0 || H <= 0 || W <= 0) { hh_set_error("hh_conv2d: bad argument"); return 1; }
     if (ci % 16 || co % 8) { hh_set_error("hh_conv2d: input channels must be a multiple of 16 and output channels of 8"); return 1; }
     if (mode == 1 && stride != 1) { hh_set_error("hh_conv2d: mode 1 is the data gradient of a stride-1 convolution"); return 1; }
+    if (ks == 2 && stride != 1) { hh_set_error("hh_conv2d: 2x2 kernels run at stride 1 only"); return 1; }
+    if (mode == 1) { pad_y = ks - 1 - pad_y; pad_x = ks - 1 - pad_x; }  // the adjoint correlates with the rotated kernel
     if (mode == 2 && (stride != 2 || ks != 3)) { hh_set_error("hh_conv2d: mode 2 is the data gradient of a 3x3 stride-2 convolution"); return 1; }
     const int coutp = round_up_i(co, 32);
     const int kks = mode == 2 ? 2 : ks, kstride = mode == 2 ? 1 : stride;  // kernel that actually runs
@@ -206,7 +210,7 @@ int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int c
     p.out = (bf16_raw *)y; p.out_cs = co;
     p.Ho = Ho; p.Wo = Wo; p.Hob = Ho; p.Wob = Wo; p.osy = p.osx = 1;
     p.cin = cin_pad; p.cout_real = co; p.cout_store = co; p.relu = relu;
-    p.pad_y = p.pad_x = (ks - 1) / 2; p.B = B;
+    p.pad_y = pad_y; p.pad_x = pad_x; p.B = B;
     p.tiles_x = (Wo + cc.TW - 1) / cc.TW; p.tiles_y = (Ho + cc.th() - 1) / cc.th(); p.ncg = coutp / cc.cout_t();
     if (mode == 2) {  // four output-parity phases, each a 2x2 conv over dL/dy scattered onto the 2H x 2W grid
         p.Hob = 2 * H; p.Wob = 2 * W; p.osy = p.osx = 2; p.pad_y = p.pad_x = 0;
@@ -228,15 +232,18 @@ int64_t hh_conv2d_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, 
     return (int64_t)conv_wgrad_num_workers(B, Ho, Wo, stride) * ks * ks * round_up_i(cout, 64) * round_up_i(cin, 64) * 4;
 }
 
-int hh_conv2d_wgrad(const void *x, const void *dy, int B, int H, int W, int cin, int cout, int ks, int stride, float *dw, void *workspace,
-                    void *stream)
+int hh_conv2d_wgrad(const void *x, const void *dy, int B, int H, int W, int cin, int cout, int ks, int stride, int pad_y, int pad_x, float *dw,
+                    void *workspace, void *stream)
 {
+    if (pad_y < 0) pad_y = (ks - 1) / 2;
+    if (pad_x < 0) pad_x = (ks - 1) / 2;
     if (!x || !dy || !dw || !workspace || B <= 0 || H <= 0 || W <= 0) { hh_set_error("hh_conv2d_wgrad: bad argument"); return 1; }
     if (cin % 8 || cout % 8) { hh_set_error("hh_conv2d_wgrad: channel counts must be multiples of 8"); return 1; }
-    if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1))) { hh_set_error("hh_conv2d_wgrad: 3x3 (stride 1 or 2) and 1x1 (stride 1) only"); return 1; }
+    if (!((ks == 3 && (stride == 1 || stride == 2)) || ((ks == 1 || ks == 2) && stride == 1))) { hh_set_error("hh_conv2d_wgrad: 3x3 (stride 1 or 2), 2x2 and 1x1 (stride 1) only"); return 1; }
     WgradParams p{};
     p.x = (const bf16_raw *)x; p.dy = (const bf16_raw *)dy; p.partial = (float *)workspace;
     p.B = B; p.H = H; p.W = W; p.Ho = stride == 2 ? H / 2 : H; p.Wo = stride == 2 ? W / 2 : W; p.cin = cin; p.cout = cout;
+    p.pad_y = pad_y; p.pad_x = pad_x;
     HH_CHECK_HIP(conv_wgrad_launch(p, ks, stride, dw, (hipStream_t)stream));
     return 0;
 }

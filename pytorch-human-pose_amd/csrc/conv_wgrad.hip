@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, hh = g >> 1;
     const int ncib = (p.cin + 63) / 64;
     const int co0 = (blockIdx.y / ncib) * 64, ci0 = (blockIdx.y % ncib) * 64;  // channel block of this workgroup
-    const int pad = (KS - 1) / 2;
+    const int pad_y = p.pad_y, pad_x = p.pad_x;
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH, ntiles = p.B * tiles_y * tiles_x;
 
     f32x16 acc[NTAP];
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         const int tx = r % tiles_x; r /= tiles_x;
         const int ty = r % tiles_y;
         const int b = r / tiles_y;
-        const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
+        const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
         // ---- stage dY tile and X patch: [pixel][64 channels], zero outside the image / beyond the channel count
         u32x4 yreg[NYL], xreg[NXL];
         sfor<NYL>([&](auto ic) {
@@ -169,6 +169,7 @@ hipError_t conv_wgrad_launch(const WgradParams &p, int ks, int stride, float *dw
     if (ks == 3 && stride == 1) e = launch_one<3, 1, 32>(p, nwg, s);
     else if (ks == 1 && stride == 1) e = launch_one<1, 1, 32>(p, nwg, s);
     else if (ks == 3 && stride == 2) e = launch_one<3, 2, 16>(p, nwg, s);
+    else if (ks == 2 && stride == 1) e = launch_one<2, 1, 32>(p, nwg, s);
     if (e != hipSuccess) return e;
     const int coutp = (p.cout + 63) / 64 * 64, cinp = (p.cin + 63) / 64 * 64, ntap = ks * ks;
     const size_t total = (size_t)p.cout * p.cin * ntap;

@@ -147,6 +147,7 @@ struct WgradParams {
     const bf16_raw *dy;  // [B,Ho,Wo,cout]
     float *partial;      // workspace: workers * ks*ks * roundup(cout,64) * roundup(cin,64) floats
     int B, H, W, Ho, Wo, cin, cout;
+    int pad_y, pad_x;    // top / left zero padding of x
 };
 #define HH_WGRAD_WORKERS 128  // persistent pixel-tile workers per channel block
 int conv_wgrad_num_workers(int B, int Ho, int Wo, int stride);

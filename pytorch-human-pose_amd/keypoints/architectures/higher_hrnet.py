@@ -137,6 +137,12 @@ class HigherHRNet(EngineModule):
         return init, dec
 
     def forward(self, images: Tensor) -> tuple[list[Tensor], Tensor]:
+        if self.training:  # batch-stat BatchNorm, differentiable: keypoints/train_net.py on the training kernels
+            from ..train_net import higher_hrnet_train_forward
+            if not images.is_cuda:
+                raise _lib.HHError("HigherHRNet forward needs a CUDA/HIP tensor: there is no CPU path")
+            self._dirty = True  # parameters / running statistics change under training: re-fold before the next eval forward
+            return higher_hrnet_train_forward(self, images)
         init, dec = self.forward_raw(images)
         K = self.num_kpts
         return [init[:, :K], dec[:, :K]], init[:, K:]

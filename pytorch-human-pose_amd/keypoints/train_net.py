@@ -1,0 +1,200 @@
+"""Train-mode forward of HigherHRNet on the HIP building blocks.
+
+The layer graph is the reference's (`src/keypoints/architectures/hrnet.py:29-385`, `higher_hrnet.py:7-81`), walked over
+the shim's parameter tree.  Convolutions (forward, data gradient, weight gradient) and train-mode BatchNorm (+ residual,
++ ReLU, forward and backward) are `torch.autograd.Function`s over the C-ABI ops of `train_ops`; torch autograd is only the
+tape, and the glue between kernels (nearest upsample, sums of the fusion layers, channel concat / slicing, bias adds) are
+torch elementwise ops on the same bf16 channels_last tensors.  Activations are bf16 (the reference trains under fp16
+autocast, `module.py:50`), parameters and their gradients fp32, so torch optimizers, GradScaler-free bf16 training and
+DistributedDataParallel (gradient all-reduce over RCCL) work on the module unchanged.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import train_ops as ops
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, stride: int, pad):
+        ctx.save_for_backward(x, w)
+        ctx.stride, ctx.pad = stride, pad
+        return ops.conv2d(x, w, stride, pad=pad)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = ops.conv2d(dy, w, ctx.stride, data_grad=True, pad=ctx.pad) if ctx.needs_input_grad[0] else None
+        dw = ops.conv2d_weight_grad(x, dy, w.shape[-1], ctx.stride, pad=ctx.pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+class _BNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, res, relu: bool, eps: float, stats: list):
+        y, mean, invstd = ops.bn_train_forward(x, gamma, beta, eps, res, relu)
+        ctx.save_for_backward(x, y, mean, invstd, gamma)
+        ctx.relu, ctx.has_res = relu, res is not None
+        stats.append((mean, invstd))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta, dres = ops.bn_train_backward(x, y, dy.contiguous(memory_format=torch.channels_last), mean, invstd, gamma,
+                                                        ctx.relu, want_dres=ctx.has_res)
+        return dx, dgamma, dbeta, dres, None, None, None
+
+
+def _pad_c(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def conv(x: Tensor, m: nn.Conv2d, stride: int | None = None) -> Tensor:
+    """nn.Conv2d forward on the HIP kernels.  Channel counts the kernels cannot take (3, 17, 34, 66 ...) are zero padded:
+    padding and slicing are differentiable torch ops, so the gradients reach the unpadded parameter."""
+    w = m.weight
+    cout, cin, ks, _ = w.shape
+    stride = m.stride[0] if stride is None else stride
+    cin_p, cout_p = _pad_c(cin, 16), _pad_c(cout, 16)  # the data gradient runs the conv with the roles swapped
+    if cin_p != cin or cout_p != cout:
+        w = F.pad(w, (0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout))
+    if x.shape[1] != cin_p:
+        x = F.pad(x, (0, 0, 0, 0, 0, cin_p - x.shape[1]))
+    y = _ConvFn.apply(x.contiguous(memory_format=torch.channels_last), w, stride, None)
+    if cout_p != cout:
+        y = y[:, :cout]
+    if m.bias is not None:
+        y = y + m.bias.view(1, -1, 1, 1).to(y.dtype)
+    return y
+
+
+def bn(x: Tensor, m: nn.BatchNorm2d, relu: bool = False, res: Tensor | None = None) -> Tensor:
+    """nn.BatchNorm2d in training mode (+ residual, + ReLU); updates the running statistics like torch does."""
+    stats: list = []
+    y = _BNFn.apply(x.contiguous(memory_format=torch.channels_last), m.weight, m.bias,
+                    res.contiguous(memory_format=torch.channels_last) if res is not None else None, relu, m.eps, stats)
+    if m.track_running_stats and m.running_mean is not None:
+        with torch.no_grad():
+            mean, invstd = stats[0]
+            P = x.shape[0] * x.shape[2] * x.shape[3]
+            var_unbiased = (1.0 / (invstd * invstd) - m.eps) * (P / max(P - 1, 1))
+            mom = m.momentum if m.momentum is not None else 0.1
+            m.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            m.running_var.mul_(1 - mom).add_(var_unbiased, alpha=mom)
+            m.num_batches_tracked += 1
+    return y
+
+
+def deconv_k4s2(x: Tensor, m: nn.ConvTranspose2d) -> Tensor:
+    """ConvTranspose2d(k=4, s=2, p=1, bias=False) (higher_hrnet.py:21-24) as four output-parity 2x2 convolutions: output
+    row 2i+py takes input rows (i-1, i) with kernel rows (3, 1) when py = 0 and rows (i, i+1) with kernel rows (2, 0) when
+    py = 1 (same in x).  The phase kernels are index views of the parameter, so autograd assembles its gradient."""
+    wt = m.weight  # [cin, cout, 4, 4]
+    cin, cout = wt.shape[:2]
+    cin_p, cout_p = _pad_c(cin, 16), _pad_c(cout, 16)  # the data gradient runs the conv with the roles swapped
+    if x.shape[1] != cin_p:
+        x = F.pad(x, (0, 0, 0, 0, 0, cin_p - x.shape[1]))
+    x = x.contiguous(memory_format=torch.channels_last)
+    B, _, H, W = x.shape
+    y = torch.zeros((B, cout, 2 * H, 2 * W), device=x.device, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    for py in range(2):
+        for px in range(2):
+            ky = [3, 1] if py == 0 else [2, 0]
+            kx = [3, 1] if px == 0 else [2, 0]
+            w = wt[:, :, ky][:, :, :, kx].permute(1, 0, 2, 3)  # [cout, cin, 2, 2]
+            w = F.pad(w, (0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout))
+            yp = _ConvFn.apply(x, w.contiguous(), 1, (1 - py, 1 - px))[:, :cout]
+            y[:, :, py::2, px::2] = yp
+    return y
+
+
+# ------------------------------------------------------------------------------------------ the net
+def _bottleneck(x, u):
+    y = bn(conv(x, u.conv1), u.bn1, relu=True)
+    y = bn(conv(y, u.conv2), u.bn2, relu=True)
+    ds = u._modules.get("downsample")
+    r = bn(conv(x, ds._modules["0"]), ds._modules["1"]) if ds is not None else x
+    return bn(conv(y, u.conv3), u.bn3, relu=True, res=r)
+
+
+def _basic(x, u):
+    y = bn(conv(x, u.conv1), u.bn1, relu=True)
+    return bn(conv(y, u.conv2), u.bn2, relu=True, res=x)
+
+
+def _children(m):
+    return [m._modules[k] for k in sorted(m._modules, key=int)]
+
+
+def _fusion(xs, fl, n_out):
+    outs = []
+    for i in range(n_out):
+        row = fl.scales_fusion_layers._modules.get(str(i)) if hasattr(fl, "scales_fusion_layers") else None
+        acc = None
+        for j, x in enumerate(xs):
+            if j == i:
+                t = x
+            else:
+                q = row._modules[str(j)]
+                if j > i:
+                    t = bn(conv(x, q._modules["0"]), q._modules["1"])
+                    t = F.interpolate(t, scale_factor=2 ** (j - i), mode="nearest")
+                else:
+                    t = x
+                    for k in range(i - j):
+                        qq = q._modules[str(k)]
+                        t = bn(conv(t, qq._modules["0"]), qq._modules["1"], relu=(k != i - j - 1))
+            acc = t if acc is None else acc + t
+        outs.append(F.relu(acc))
+    return outs
+
+
+def higher_hrnet_train_forward(net, images: Tensor):
+    """-> ([hm_1/4, hm_1/2] fp32, tags_1/4 fp32), differentiable w.r.t. every parameter of `net`."""
+    K = net.num_kpts
+    bb = net.backbone
+    x = images.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = bn(conv(x, bb.conv1), bb.bn1, relu=True)
+    x = bn(conv(x, bb.conv2), bb.bn2, relu=True)
+    xs = [x]
+    nblocks = [1, 1, 4, 3]
+    for s in range(4):
+        st = bb.stages._modules[str(s)]
+        for b in range(nblocks[s]):
+            blk = st.blocks._modules[str(2 * b)]
+            unit = _bottleneck if s == 0 else _basic
+            new = []
+            for i, t in enumerate(xs):
+                for u in _children(blk.scales_blocks._modules[str(i)]):
+                    t = unit(t, u)
+                new.append(t)
+            xs = new
+            last = s == 3 and b == nblocks[s] - 1
+            if s > 0:
+                xs = _fusion(xs, st.blocks._modules[str(2 * b + 1)], 1 if last else len(xs))
+            else:
+                xs = [F.relu(xs[0])]
+        if s < 3:
+            tb = st.transition_layer.transition_blocks
+            n = len(xs)
+            q = tb._modules[str(n)]
+            newb = bn(conv(xs[-1], q._modules["0"]), q._modules["1"], relu=True)
+            if s == 0:
+                q0 = tb._modules["0"]
+                xs = [bn(conv(xs[0], q0._modules["0"]), q0._modules["1"], relu=True)]
+            xs = xs + [newb]
+    feats = xs[0]
+    init = conv(feats, net.init_heatmaps_head)
+    d = net.deconv_layers._modules["0"]
+    y = torch.cat((feats, init.to(feats.dtype)), 1)
+    y = bn(deconv_k4s2(y, d.deconv._modules["0"]), d.deconv._modules["1"], relu=True)
+    for u in _children(d.resid_blocks):
+        y = _basic(y, u)
+    out = conv(y, d.final_layer)
+    init, out = init.float(), out.float()
+    return [init[:, :K], out[:, :K]], init[:, K:]

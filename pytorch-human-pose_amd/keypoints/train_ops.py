@@ -16,7 +16,7 @@ def _nhwc(x: Tensor) -> Tensor:
 
 
 def conv2d(x: Tensor, w: Tensor, stride: int = 1, bias: Tensor | None = None, res: Tensor | None = None, relu: bool = False,
-           data_grad: bool = False) -> Tensor:
+           data_grad: bool = False, pad: tuple[int, int] | None = None) -> Tensor:
     """y = act(conv(x, w) + bias (+ res)), padding (ks-1)/2.  data_grad=True: x is dL/dy of the conv with weights
     w [cout,cin,ks,ks] and this stride, and the result is dL/dx (stride 2: 3x3 only, even input sizes)."""
     lib = _lib.load()
@@ -43,7 +43,8 @@ def conv2d(x: Tensor, w: Tensor, stride: int = 1, bias: Tensor | None = None, re
         bias = bias.detach().to(x.device, torch.float32).contiguous()
     stream = torch.cuda.current_stream(x.device).cuda_stream
     with torch.cuda.device(x.device):
-        _lib.check(lib.hh_conv2d(x.data_ptr(), B, H, W, cin, w.data_ptr(), cout, ks, stride, mode,
+        py_, px_ = pad if pad is not None else (-1, -1)
+        _lib.check(lib.hh_conv2d(x.data_ptr(), B, H, W, cin, w.data_ptr(), cout, ks, stride, mode, py_, px_,
                                  bias.data_ptr() if bias is not None else None, res.data_ptr() if res is not None else None,
                                  int(relu), y.data_ptr(), ws.data_ptr(), stream))
     return y
@@ -88,7 +89,7 @@ def bn_train_backward(x: Tensor, y: Tensor, dy: Tensor, mean: Tensor, invstd: Te
     return dx, dgamma, dbeta, dres
 
 
-def conv2d_weight_grad(x: Tensor, dy: Tensor, ks: int, stride: int = 1) -> Tensor:
+def conv2d_weight_grad(x: Tensor, dy: Tensor, ks: int, stride: int = 1, pad: tuple[int, int] | None = None) -> Tensor:
     """dL/dW [cout,cin,ks,ks] fp32 of y = conv(x, W) (padding (ks-1)/2) from the layer input x and dL/dy."""
     lib = _lib.load()
     x, dy = _nhwc(x), _nhwc(dy)
@@ -98,5 +99,6 @@ def conv2d_weight_grad(x: Tensor, dy: Tensor, ks: int, stride: int = 1) -> Tenso
     ws = torch.empty(lib.hh_conv2d_wgrad_workspace_bytes(B, H, W, cin, cout, ks, stride), device=x.device, dtype=torch.uint8)
     stream = torch.cuda.current_stream(x.device).cuda_stream
     with torch.cuda.device(x.device):
-        _lib.check(lib.hh_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), B, H, W, cin, cout, ks, stride, dw.data_ptr(), ws.data_ptr(), stream))
+        py_, px_ = pad if pad is not None else (-1, -1)
+        _lib.check(lib.hh_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), B, H, W, cin, cout, ks, stride, py_, px_, dw.data_ptr(), ws.data_ptr(), stream))
     return dw
