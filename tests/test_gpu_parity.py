@@ -488,3 +488,55 @@ def test_training_building_blocks_conv_and_batchnorm(pkg):
         close(dbeta, beta.grad, ("bn dbeta", C), 2e-2)
         if with_res:
             close(dres, res.grad, ("bn dres", C), 2e-2)
+
+
+def test_train_step_matches_reference_autograd(pkg):
+    """HigherHRNet in .train() mode on the HIP training kernels (bf16 activations, batch-statistics BatchNorm, fp32 parameter
+    gradients) against (i) the reference net in .train() mode + torch autograd (tests/golden/train_step.npz) and (ii) the
+    fp32 oracle's full gradients.  bf16 through ~110 conv+BN layers with batch statistics over 2 images: outputs within
+    8 % of max, loss within 0.5 %, gradient direction cosine > 0.85 for every parameter (median > 0.95) and norm ratios
+    within 25 %; then one Adam step and an eval-mode forward on the updated weights."""
+    g = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    K = 17
+    net = pkg.HigherHRNet(K, 32)
+    sd = {k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 5)) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    x = torch.from_numpy(pkg.synth.synth_images(2, 128, 128, seed=1))
+    hms, tags = net(x.to(DEV))
+    assert hms[0].shape == (2, K, 32, 32) and hms[1].shape == (2, K, 64, 64) and tags.shape == (2, K, 32, 32)
+    loss = (hms[0] ** 2).mean() + (hms[1] ** 2).mean() + (tags ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 5e-3 * float(g["loss"])
+    for name, t in (("hm0", hms[0]), ("hm1", hms[1]), ("tags", tags)):
+        a = t.detach().float().cpu().numpy().ravel()
+        assert np.abs(a[g[f"{name}.idx"]] - g[f"{name}.val"]).max() < 8e-2 * float(g[f"{name}.absmax"]), name
+    names = [str(n) for n in g["grad.names"]]
+    params = dict(net.named_parameters())
+    assert set(names) == set(params) and all(p.grad is not None for p in params.values())
+    ratios = np.array([params[n].grad.double().norm().item() / max(g["grad.norms"][i], 1e-30) for i, n in enumerate(names)])
+    assert np.all((ratios > 0.75) & (ratios < 1.33)) and abs(np.median(ratios) - 1) < 0.05, (ratios.min(), ratios.max())
+    # full gradients of the fp32 oracle (autograd on the CPU)
+    osd = {k: (v.clone().float().requires_grad_() if k in params else v.clone()) for k, v in sd.items()}
+    oh, ot = ofw.higher_hrnet(x, osd, K, train=True)
+    ((oh[0] ** 2).mean() + (oh[1] ** 2).mean() + (ot ** 2).mean()).backward()
+    cos = []
+    for n in names:
+        a, b = params[n].grad.float().cpu().flatten(), osd[n].grad.flatten()
+        cos.append(float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
+    assert min(cos) > 0.85 and np.median(cos) > 0.95, (min(cos), np.median(cos))
+    # BatchNorm running statistics moved the way nn.BatchNorm2d moves them (momentum 0.1, unbiased variance)
+    st = net.state_dict()
+    for k in ("backbone.bn1.running_mean", "backbone.bn1.running_var", "deconv_layers.0.deconv.1.running_mean",
+              "backbone.stages.3.blocks.4.scales_blocks.3.3.bn2.running_var"):
+        np.testing.assert_allclose(st[k].cpu().numpy(), g["stat." + k], rtol=3e-2, atol=3e-3)
+    assert int(st["backbone.bn1.num_batches_tracked"]) == 1
+    # the parameters are ordinary fp32 nn.Parameters: a torch optimizer steps them, and eval mode re-folds the new weights
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    before = params["backbone.conv1.weight"].detach().clone()
+    opt.step()
+    assert not torch.equal(before, params["backbone.conv1.weight"])
+    net.eval()
+    with torch.no_grad():
+        eh, et = net(x.to(DEV))
+    assert torch.isfinite(eh[0]).all() and torch.isfinite(eh[1]).all() and eh[0].shape == hms[0].shape

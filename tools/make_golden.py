@@ -14,6 +14,7 @@ What is imported from the reference (and therefore *pinned* by these fixtures):
   * munkres.Munkres 1.1.4                                        (assignment, a14)
   * src.base.transforms.utils.get_multi_scale_size               (resize geometry, a10)
   * src.keypoints.loss.AEKeypointsLoss                           (training loss + autograd gradients, a20)
+  * the same HigherHRNet in .train() mode + torch autograd        (train-mode forward / backward, a20)
 What is NOT importable here (cv2 / torchvision missing) and is restated inline with the
 same torch calls the reference makes: the three F.interpolate(bilinear,
 align_corners=False) + stack/mean lines of results.py:48-67,225-230 and the flip-TTA
@@ -310,8 +311,43 @@ def loss_fixtures():
     json.dump({"cases": [list(c) for c in LOSS_CASES]}, open(os.path.join(OUT, "loss_meta.json"), "w"), indent=1)
 
 
+def train_fixture():
+    """The reference HigherHRNet in .train() mode (batch-statistics BatchNorm): forward on a seeded batch, the scalar
+    mean(hm0^2) + mean(hm1^2) + mean(tags^2), torch autograd gradients of it, and the running statistics after the step."""
+    net = HigherHRNet(17, 32)
+    load_synth(net, 5)
+    net.train()
+    x = torch.from_numpy(synth.synth_images(2, 128, 128, seed=1))
+    hms, tags = net(x)
+    loss = (hms[0] ** 2).mean() + (hms[1] ** 2).mean() + (tags ** 2).mean()
+    loss.backward()
+    out = {"loss": np.float32(loss.item())}
+    rs = np.random.RandomState(3)
+    for name, t in (("hm0", hms[0]), ("hm1", hms[1]), ("tags", tags)):
+        a = t.detach().numpy().ravel()
+        idx = rs.randint(0, a.size, 256)
+        out[f"{name}.idx"], out[f"{name}.val"], out[f"{name}.absmax"] = idx.astype(np.int64), a[idx], np.float32(np.abs(a).max())
+    names, norms, samples = [], [], []
+    for name, p in net.named_parameters():
+        g = p.grad.numpy().ravel()
+        names.append(name)
+        norms.append(np.linalg.norm(g.astype(np.float64)))
+        samples.append(g[np.linspace(0, g.size - 1, 4).astype(int)])
+    out["grad.names"] = np.array(names)
+    out["grad.norms"] = np.array(norms, np.float64)
+    out["grad.samples"] = np.stack(samples).astype(np.float32)
+    sd = net.state_dict()
+    for k in ("backbone.bn1.running_mean", "backbone.bn1.running_var", "deconv_layers.0.deconv.1.running_mean",
+              "backbone.stages.3.blocks.4.scales_blocks.3.3.bn2.running_var"):
+        out["stat." + k] = sd[k].numpy()
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
+    print("train fixture: loss", out["loss"], "params", len(names))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "decode", "flip", "munkres", "geometry", "loss"]
+    which = sys.argv[1:] or ["net", "decode", "flip", "munkres", "geometry", "loss", "train"]
+    if "train" in which:
+        train_fixture()
     if "loss" in which:
         loss_fixtures()
     if "munkres" in which:
