@@ -83,8 +83,8 @@ class EngineModule(nn.Module):
     def _check_input(self, images: Tensor) -> Tensor:
         if self.training:
             raise NotImplementedError(
-                f"{type(self).__name__} (MI355X engine): the training forward/backward (SURVEY.md §8 a20-a21) is not "
-                "built yet; call .eval() for inference"
+                f"{type(self).__name__}: the fused inference engine folds BatchNorm and keeps no gradients; in .train() mode call "
+                "the module (forward), which runs keypoints/train_net.py, or .eval() first"
             )
         if not images.is_cuda:
             raise _lib.HHError(f"{type(self).__name__} forward needs a CUDA/HIP tensor: there is no CPU path")

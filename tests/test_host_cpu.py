@@ -61,8 +61,10 @@ def test_no_cpu_fallback(pkg):
     net = pkg.HigherHRNet(17, 32).eval()
     with pytest.raises(pkg._lib.HHError):
         net(torch.zeros(1, 3, 64, 64))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(pkg._lib.HHError):  # the training forward runs on the HIP kernels as well: no CPU path either
         pkg.HigherHRNet(17, 32).train()(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(NotImplementedError):  # the raw engine entry point is inference only
+        pkg.HigherHRNet(17, 32).train().forward_raw(torch.zeros(1, 3, 64, 64))
     with pytest.raises(pkg._lib.HHError):
         pkg.MPPEHeatmapParser(17).parse(torch.zeros(17, 64, 64), torch.zeros(17, 64, 64, 1))
 
