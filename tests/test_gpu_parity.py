@@ -540,3 +540,34 @@ def test_train_step_matches_reference_autograd(pkg):
     with torch.no_grad():
         eh, et = net(x.to(DEV))
     assert torch.isfinite(eh[0]).all() and torch.isfinite(eh[1]).all() and eh[0].shape == hms[0].shape
+
+
+def test_train_step_under_distributed_data_parallel(pkg):
+    """base/model.py:36-48 wraps the net in DistributedDataParallel: the HIP training forward must survive the wrapper
+    (parameter registration, autograd hooks firing on the custom Functions' parameter gradients, bucketed all-reduce on
+    RCCL).  One rank here (one GPU per box): the reduced gradients must equal the plain module's."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    K = 17
+    def make():
+        net = pkg.HigherHRNet(K, 32)
+        net.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 5)) for k, v in net.state_dict().items()})
+        return net.to(DEV).train()
+    x = torch.from_numpy(pkg.synth.synth_images(2, 64, 64, seed=2)).to(DEV)
+    def grads(m):
+        hms, tags = m(x)
+        ((hms[0] ** 2).mean() + (hms[1] ** 2).mean() + (tags ** 2).mean()).backward()
+    plain = make()
+    grads(plain)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        ddp = DDP(make(), device_ids=[0])
+        grads(ddp)
+        torch.cuda.synchronize()
+        for (n, a), (_, b) in zip(plain.named_parameters(), ddp.module.named_parameters()):
+            assert b.grad is not None and torch.equal(a.grad, b.grad), n
+    finally:
+        if created:
+            dist.destroy_process_group()
