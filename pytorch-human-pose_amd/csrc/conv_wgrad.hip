@@ -136,9 +136,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         const int tap = (int)(i % ntap);
         const int ci = (int)((i / ntap) % cin), co = (int)(i / ntap / cin);
         const size_t o = ((size_t)tap * coutp + co) * cinp + ci, stride = (size_t)ntap * coutp * cinp;
-        float s = 0.f;
-        for (int w = 0; w < nwg; ++w) s += part[(size_t)w * stride + o];
-        dw[i] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains keep four loads in flight (fixed order)
+        int w = 0;
+        for (; w + 3 < nwg; w += 4) {
+            s0 += part[(size_t)w * stride + o]; s1 += part[(size_t)(w + 1) * stride + o];
+            s2 += part[(size_t)(w + 2) * stride + o]; s3 += part[(size_t)(w + 3) * stride + o];
+        }
+        for (; w < nwg; ++w) s0 += part[(size_t)w * stride + o];
+        dw[i] = (s0 + s1) + (s2 + s3);
     }
 }
 

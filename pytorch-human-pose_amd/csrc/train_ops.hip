@@ -85,13 +85,22 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const bf16_raw *__restr
         partial[((size_t)blockIdx.x * C + c) * 2 + 1] = b;
     }
 }
-__global__ void bn_finalize_kernel(const double *__restrict__ partial, int nblocks, int C, double P, float eps, float *__restrict__ mean,
-                                   float *__restrict__ invstd)
+// one wave per channel: lane l adds partials l, l+64, ... and a shuffle tree finishes (fixed order: deterministic)
+__device__ __forceinline__ void sum_partials_wave(const double *__restrict__ partial, int nblocks, int C, int c, double &a, double &b)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    a = 0; b = 0;
+    for (int i = threadIdx.x & 63; i < nblocks; i += 64) { a += partial[((size_t)i * C + c) * 2]; b += partial[((size_t)i * C + c) * 2 + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+}
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restrict__ partial, int nblocks, int C, double P, float eps,
+                                                          float *__restrict__ mean, float *__restrict__ invstd)
+{
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double a = 0, b = 0;
-    for (int i = 0; i < nblocks; ++i) { a += partial[((size_t)i * C + c) * 2]; b += partial[((size_t)i * C + c) * 2 + 1]; }
+    double a, b;
+    sum_partials_wave(partial, nblocks, C, c, a, b);
+    if (threadIdx.x & 63) return;
     const double m = a / P, var = b / P - m * m;  // biased variance, as F.batch_norm normalises with
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
@@ -133,7 +142,7 @@ hipError_t launch_bn_train_forward(const bf16_raw *x, int cs, size_t P, int C, c
 {
     const int nblocks = HH_BN_BLOCKS;
     hipLaunchKernelGGL(bn_partial_kernel, dim3(nblocks), dim3(256), 0, s, x, cs, P, C, scratch);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, nblocks, C, (double)P, eps, mean, invstd);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, scratch, nblocks, C, (double)P, eps, mean, invstd);
     unsigned grid = (unsigned)((P * (C / 8) + 255) / 256);
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, s, x, cs, P, C, mean, invstd, gamma, beta, res, relu, y);
@@ -181,13 +190,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const bf16_raw *__r
         partial[((size_t)blockIdx.x * C + c) * 2 + 1] = b;
     }
 }
-__global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblocks, int C, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblocks, int C,
+                                                              float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double a = 0, b = 0;
-    for (int i = 0; i < nblocks; ++i) { a += partial[((size_t)i * C + c) * 2]; b += partial[((size_t)i * C + c) * 2 + 1]; }
+    double a, b;
+    sum_partials_wave(partial, nblocks, C, c, a, b);
+    if (threadIdx.x & 63) return;
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
 }
@@ -237,7 +247,7 @@ hipError_t launch_bn_train_backward(const bf16_raw *x, const bf16_raw *y, const 
 {
     const int nblocks = HH_BN_BLOCKS;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblocks), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, relu, scratch);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, nblocks, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, scratch, nblocks, C, dgamma, dbeta);
     unsigned grid = (unsigned)((P * (C / 8) + 255) / 256);
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, dgamma, dbeta, relu, dx, dres);

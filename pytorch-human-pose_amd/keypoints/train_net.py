@@ -73,21 +73,42 @@ def conv(x: Tensor, m: nn.Conv2d, stride: int | None = None) -> Tensor:
     return y
 
 
+_PENDING_STATS: list = []  # (module, batch mean, batch invstd, pixels) of the forward in flight, applied by flush_running_stats
+
+
 def bn(x: Tensor, m: nn.BatchNorm2d, relu: bool = False, res: Tensor | None = None) -> Tensor:
-    """nn.BatchNorm2d in training mode (+ residual, + ReLU); updates the running statistics like torch does."""
+    """nn.BatchNorm2d in training mode (+ residual, + ReLU); the running statistics are updated like torch updates them,
+    once per forward for all layers together (flush_running_stats)."""
     stats: list = []
     y = _BNFn.apply(x.contiguous(memory_format=torch.channels_last), m.weight, m.bias,
                     res.contiguous(memory_format=torch.channels_last) if res is not None else None, relu, m.eps, stats)
     if m.track_running_stats and m.running_mean is not None:
-        with torch.no_grad():
-            mean, invstd = stats[0]
-            P = x.shape[0] * x.shape[2] * x.shape[3]
-            var_unbiased = (1.0 / (invstd * invstd) - m.eps) * (P / max(P - 1, 1))
+        _PENDING_STATS.append((m, stats[0][0], stats[0][1], x.shape[0] * x.shape[2] * x.shape[3]))
+    return y
+
+
+@torch.no_grad()
+def flush_running_stats() -> None:
+    """running = (1 - momentum) * running + momentum * batch statistic (unbiased variance), num_batches_tracked += 1, for
+    every BatchNorm of the forward in a handful of multi-tensor launches instead of six tiny ones per layer."""
+    if not _PENDING_STATS:
+        return
+    mods = [t[0] for t in _PENDING_STATS]
+    moms = {(m.momentum if m.momentum is not None else 0.1) for m in mods}
+    means = [t[1] for t in _PENDING_STATS]
+    var_unb = [(1.0 / (t[2] * t[2]) - t[0].eps) * (t[3] / max(t[3] - 1, 1)) for t in _PENDING_STATS]
+    if len(moms) == 1:
+        mom = moms.pop()
+        rm, rv = [m.running_mean for m in mods], [m.running_var for m in mods]
+        torch._foreach_mul_(rm, 1 - mom); torch._foreach_add_(rm, means, alpha=mom)
+        torch._foreach_mul_(rv, 1 - mom); torch._foreach_add_(rv, var_unb, alpha=mom)
+    else:
+        for m, mean, vu in zip(mods, means, var_unb):
             mom = m.momentum if m.momentum is not None else 0.1
             m.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-            m.running_var.mul_(1 - mom).add_(var_unbiased, alpha=mom)
-            m.num_batches_tracked += 1
-    return y
+            m.running_var.mul_(1 - mom).add_(vu, alpha=mom)
+    torch._foreach_add_([m.num_batches_tracked for m in mods], 1)
+    _PENDING_STATS.clear()
 
 
 def deconv_k4s2(x: Tensor, m: nn.ConvTranspose2d) -> Tensor:
@@ -101,7 +122,7 @@ def deconv_k4s2(x: Tensor, m: nn.ConvTranspose2d) -> Tensor:
         x = F.pad(x, (0, 0, 0, 0, 0, cin_p - x.shape[1]))
     x = x.contiguous(memory_format=torch.channels_last)
     B, _, H, W = x.shape
-    y = torch.zeros((B, cout, 2 * H, 2 * W), device=x.device, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = torch.empty((B, cout, 2 * H, 2 * W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)  # every phase is written
     for py in range(2):
         for px in range(2):
             ky = [3, 1] if py == 0 else [2, 0]
@@ -158,6 +179,7 @@ def higher_hrnet_train_forward(net, images: Tensor):
     """-> ([hm_1/4, hm_1/2] fp32, tags_1/4 fp32), differentiable w.r.t. every parameter of `net`."""
     K = net.num_kpts
     bb = net.backbone
+    _PENDING_STATS.clear()
     x = images.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     x = bn(conv(x, bb.conv1), bb.bn1, relu=True)
     x = bn(conv(x, bb.conv2), bb.bn2, relu=True)
@@ -196,5 +218,6 @@ def higher_hrnet_train_forward(net, images: Tensor):
     for u in _children(d.resid_blocks):
         y = _basic(y, u)
     out = conv(y, d.final_layer)
+    flush_running_stats()
     init, out = init.float(), out.float()
     return [init[:, :K], out[:, :K]], init[:, K:]

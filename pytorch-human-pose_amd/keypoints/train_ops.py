@@ -32,7 +32,7 @@ def conv2d(x: Tensor, w: Tensor, stride: int = 1, bias: Tensor | None = None, re
         Ho, Wo = 2 * H, 2 * W  # dL/dx of a stride-2 conv lives on the input grid
     else:
         Ho, Wo = (H // 2, W // 2) if stride == 2 else (H, W)
-    y = torch.empty((B, co, Ho, Wo), device=x.device, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = torch.empty((B, co, Ho, Wo), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
     nbytes = lib.hh_conv2d_workspace_bytes(cin, cout, ks, mode)
     if nbytes < 0:
         raise _lib.HHError("conv2d: no kernel family for this shape")
