@@ -127,23 +127,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             }
 }
 
-// dW[co][ci][tap] = sum over workgroups (fixed order) of part[wg][tap][co][ci]
+// dW[co][ci][tap] = sum over workgroups (fixed order) of part[wg][tap][co][ci].  One thread = 4 consecutive ci of one
+// (tap, co): 16-byte loads, two independent accumulator sets so that eight loads are in flight per thread.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int nwg, int ntap, int cout, int cin, int coutp,
                                                            int cinp, float *__restrict__ dw)
 {
-    const size_t total = (size_t)cout * cin * ntap;
+    const int cq = cinp / 4;
+    const size_t total = (size_t)ntap * cout * cq, stride = (size_t)ntap * coutp * cinp;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int tap = (int)(i % ntap);
-        const int ci = (int)((i / ntap) % cin), co = (int)(i / ntap / cin);
-        const size_t o = ((size_t)tap * coutp + co) * cinp + ci, stride = (size_t)ntap * coutp * cinp;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains keep four loads in flight (fixed order)
+        const int c4 = (int)(i % cq) * 4;
+        const int co = (int)((i / cq) % cout), tap = (int)(i / cq / cout);
+        const float *src = part + ((size_t)tap * coutp + co) * cinp + c4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
         int w = 0;
-        for (; w + 3 < nwg; w += 4) {
-            s0 += part[(size_t)w * stride + o]; s1 += part[(size_t)(w + 1) * stride + o];
-            s2 += part[(size_t)(w + 2) * stride + o]; s3 += part[(size_t)(w + 3) * stride + o];
+        for (; w + 1 < nwg; w += 2) {
+            const float4 u = *reinterpret_cast<const float4 *>(src + (size_t)w * stride);
+            const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)(w + 1) * stride);
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
         }
-        for (; w < nwg; ++w) s0 += part[(size_t)w * stride + o];
-        dw[i] = (s0 + s1) + (s2 + s3);
+        if (w < nwg) {
+            const float4 u = *reinterpret_cast<const float4 *>(src + (size_t)w * stride);
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        }
+        const float r[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c4 + j < cin) dw[((size_t)co * cin + c4 + j) * ntap + tap] = r[j];
     }
 }
 
@@ -160,16 +170,22 @@ static hipError_t launch_one(const WgradParams &p, int nwg, hipStream_t s)
     return hipGetLastError();
 }
 
-int conv_wgrad_num_workers(int B, int Ho, int Wo, int stride)
+// Persistent pixel-tile workers per 64x64 channel block: enough workgroups to fill the chip (>= 512 over all channel
+// blocks), but no more partial-sum sets than that, since every one is 9 x 64 x 64 floats the reduction has to read back.
+int conv_wgrad_num_workers(int B, int Ho, int Wo, int stride, int cin, int cout)
 {
     const int TW = stride == 2 ? 16 : 32;
     const int ntiles = B * ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW);
-    return ntiles < HH_WGRAD_WORKERS ? ntiles : HH_WGRAD_WORKERS;
+    const int nblocks = ((cin + 63) / 64) * ((cout + 63) / 64);
+    int want = (HH_WGRAD_WORKERS * 4 + nblocks - 1) / nblocks;
+    if (want < HH_WGRAD_WORKERS / 2) want = HH_WGRAD_WORKERS / 2;
+    if (want > HH_WGRAD_WORKERS * 4) want = HH_WGRAD_WORKERS * 4;
+    return ntiles < want ? ntiles : want;
 }
 
 hipError_t conv_wgrad_launch(const WgradParams &p, int ks, int stride, float *dw, hipStream_t s)
 {
-    const int nwg = conv_wgrad_num_workers(p.B, p.Ho, p.Wo, stride);
+    const int nwg = conv_wgrad_num_workers(p.B, p.Ho, p.Wo, stride, p.cin, p.cout);
     hipError_t e = hipErrorInvalidValue;
     if (ks == 3 && stride == 1) e = launch_one<3, 1, 32>(p, nwg, s);
     else if (ks == 1 && stride == 1) e = launch_one<1, 1, 32>(p, nwg, s);
@@ -177,9 +193,9 @@ hipError_t conv_wgrad_launch(const WgradParams &p, int ks, int stride, float *dw
     else if (ks == 2 && stride == 1) e = launch_one<2, 1, 32>(p, nwg, s);
     if (e != hipSuccess) return e;
     const int coutp = (p.cout + 63) / 64 * 64, cinp = (p.cin + 63) / 64 * 64, ntap = ks * ks;
-    const size_t total = (size_t)p.cout * p.cin * ntap;
+    const size_t total = (size_t)ntap * p.cout * (cinp / 4);
     unsigned grid = (unsigned)((total + 255) / 256);
-    if (grid > 2048) grid = 2048;
+    if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, p.partial, nwg, ntap, p.cout, p.cin, coutp, cinp, dw);
     return hipGetLastError();
 }

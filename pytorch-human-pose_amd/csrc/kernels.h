@@ -149,6 +149,6 @@ struct WgradParams {
     int B, H, W, Ho, Wo, cin, cout;
     int pad_y, pad_x;    // top / left zero padding of x
 };
-#define HH_WGRAD_WORKERS 128  // persistent pixel-tile workers per channel block
-int conv_wgrad_num_workers(int B, int Ho, int Wo, int stride);
+#define HH_WGRAD_WORKERS 128  // base count of persistent pixel-tile workers per channel block (64 .. 512, see conv_wgrad_num_workers)
+int conv_wgrad_num_workers(int B, int Ho, int Wo, int stride, int cin, int cout);
 hipError_t conv_wgrad_launch(const WgradParams &p, int ks, int stride, float *dw, hipStream_t s);
