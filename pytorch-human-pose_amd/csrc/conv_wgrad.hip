@@ -57,44 +57,52 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     // byte offsets of this lane's transposed reads inside a tile (row part added per k-step)
     const int ycol = (tco * 32 + 16 * (g & 1) + 4 * pp) * 2, xcol = (tci * 32 + 16 * (g & 1) + 4 * pp) * 2;
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // ---- staging registers: the next tile's dY tile and X patch are loaded while the current tile is multiplied; the
+    //      zero padding (image border, channels beyond the count) is applied when the registers go to LDS, so that no
+    //      load result is touched next to its issue
+    u32x4 yreg[NYL], xreg[NXL];
+    unsigned ymask = 0, xmask = 0;
+    auto issue_loads = [&](int t) {
         int r = t;
         const int tx = r % tiles_x; r /= tiles_x;
         const int ty = r % tiles_y;
         const int b = r / tiles_y;
         const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
-        // ---- stage dY tile and X patch: [pixel][64 channels], zero outside the image / beyond the channel count
-        u32x4 yreg[NYL], xreg[NXL];
+        ymask = 0; xmask = 0;
         sfor<NYL>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int u = tid + 256 * i, px = u >> 3, part = u & 7;
             const int oy = oy0 + px / TW, ox = ox0 + px % TW, c = co0 + part * 8;
-            const bool ok = (u < Y_UNITS) & (oy < p.Ho) & (ox < p.Wo) & (c < p.cout);
+            const bool ok = (t < ntiles) & (u < Y_UNITS) & (oy < p.Ho) & (ox < p.Wo) & (c < p.cout);
             const size_t off = ok ? (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.cout + c : 0;
             yreg[i] = *reinterpret_cast<const u32x4 *>(p.dy + off);
-            if (!ok) yreg[i] = u32x4{0u, 0u, 0u, 0u};
+            ymask |= ok ? (1u << i) : 0u;
         });
         sfor<NXL>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int u = tid + 256 * i, px = u >> 3, part = u & 7;
             const int iy = iy0 + px / PW, ix = ix0 + px % PW, c = ci0 + part * 8;
-            const bool ok = (u < X_UNITS) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W) & (c < p.cin);
+            const bool ok = (t < ntiles) & (u < X_UNITS) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W) & (c < p.cin);
             const size_t off = ok ? (((size_t)b * p.H + iy) * p.W + ix) * p.cin + c : 0;
             xreg[i] = *reinterpret_cast<const u32x4 *>(p.x + off);
-            if (!ok) xreg[i] = u32x4{0u, 0u, 0u, 0u};
+            xmask |= ok ? (1u << i) : 0u;
         });
+    };
+    issue_loads(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         __syncthreads();  // the previous tile's reads are done
         sfor<NYL>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int u = tid + 256 * i;
-            if (u < Y_UNITS) *reinterpret_cast<u32x4 *>(ldsY + (u >> 3) * RS + (u & 7) * 16) = yreg[i];
+            if (u < Y_UNITS) *reinterpret_cast<u32x4 *>(ldsY + (u >> 3) * RS + (u & 7) * 16) = (ymask >> i) & 1u ? yreg[i] : u32x4{0u, 0u, 0u, 0u};
         });
         sfor<NXL>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int u = tid + 256 * i;
-            if (u < X_UNITS) *reinterpret_cast<u32x4 *>(ldsX + (u >> 3) * RS + (u & 7) * 16) = xreg[i];
+            if (u < X_UNITS) *reinterpret_cast<u32x4 *>(ldsX + (u >> 3) * RS + (u & 7) * 16) = (xmask >> i) & 1u ? xreg[i] : u32x4{0u, 0u, 0u, 0u};
         });
         __syncthreads();
+        issue_loads(t + gridDim.x);  // in flight during the MFMA loop below (degenerate reads of element 0 past the last tile)
         // ---- contraction over the tile's pixels, 16 per MFMA k-step (one half row of TW = 32, or a row of TW = 16)
 #pragma unroll
         for (int y = 0; y < TH; ++y)
