@@ -96,6 +96,69 @@ def cpu_baseline(pkg, sd, maps, fwd_images=4, dec_images=8):
     }
 
 
+def train_bench(args, pkg, dist, rank, world, dev):
+    """Training step of configs[2] (keypoints/module.py:43-71): per-GPU batch `--batch` (32 x 8 GPUs = the global batch 256),
+    synthetic images and targets, bf16 activations.  One step = forward (batch-statistics BN) + AEKeypointsLoss + backward +
+    Adam; under torchrun the net is wrapped in DistributedDataParallel (gradient all-reduce on RCCL, overlapped with the
+    backward by torch's bucketing).  Prints one JSON line like the inference bench (no roofline: the step is a mix of kernels)."""
+    B, S, K = args.batch, 512, 17
+    net = pkg.HigherHRNet(K, 32)
+    net.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()})
+    net = net.to(dev).train()
+    model = net
+    if dist is not None:
+        from torch.nn.parallel import DistributedDataParallel
+        model = DistributedDataParallel(net, device_ids=[dev.index])
+    loss_fn = pkg.AEKeypointsLoss()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    x = torch.from_numpy(pkg.synth.synth_images(B, S, S, seed=rank)).to(dev)
+    hms, masks, joints = pkg.synth.synth_train_targets(B, K, S, args.people, seed=rank)
+    hms = [torch.from_numpy(h).to(dev) for h in hms]
+    masks = [torch.from_numpy(m).to(dev) for m in masks]
+
+    def step():
+        ph, pt = model(x)
+        hl, push, pull = loss_fn.calculate_loss(ph, pt, hms, masks, joints)
+        loss = hl[0] + hl[1] + push[0] + pull[0]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(max(args.warmup, 1)):
+        loss = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec (training step) HigherHRNet-W32 512px", "value": round(world * B * args.steps / elapsed, 2),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"HigherHRNet-W32 training step, batch {B} @ 512x512 per GPU: forward (train-mode BN) + AE loss + "
+                                   f"backward + Adam, {args.people} people/image", "global_batch": world * B,
+                       "parallelism": f"DistributedDataParallel x{world} (gradient all-reduce on RCCL)" if world > 1 else "single GPU",
+                       "final_loss": round(float(loss.item()), 5),
+                       "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)},
+        }), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +172,9 @@ def main():
     ap.add_argument("--single-lane", action="store_true",
                     help="no internal branch streams: kernels run one after another (what the roofline probe and the "
                          "isolated-kernel rocprofv3 pass measure)")
+    ap.add_argument("--train", action="store_true",
+                    help="time the training step of BASELINE.json configs[2] instead (forward with train-mode BN + AE loss + "
+                         "backward + Adam, DistributedDataParallel over RCCL when launched on several GPUs); not the headline metric")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,6 +190,8 @@ def main():
     pkg = importlib.import_module(PKG)
 
     B, H, W, K = args.batch, 512, 512, 17
+    if args.train:
+        return train_bench(args, pkg, dist, rank, world, dev)
     net = pkg.HigherHRNet(K, 32)
     sd = {k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()}
     net.load_state_dict(sd)
