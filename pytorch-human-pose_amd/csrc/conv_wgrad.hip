@@ -10,6 +10,8 @@
 // reduces in a fixed order (deterministic, no atomics).
 #include "kernels.h"
 
+#include <utility>
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short i16x4 __attribute__((ext_vector_type(4)));
 typedef short i16x8 __attribute__((ext_vector_type(8)));
