@@ -229,7 +229,7 @@ int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int c
 int64_t hh_conv2d_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int ks, int stride)
 {
     const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
-    return (int64_t)conv_wgrad_num_workers(B, Ho, Wo, stride, cin, cout) * ks * ks * round_up_i(cout, 64) * round_up_i(cin, 64) * 4;
+    return (int64_t)(conv_wgrad_num_workers(B, Ho, Wo, stride, cin, cout) + 16) * ks * ks * round_up_i(cout, 64) * round_up_i(cin, 64) * 4;  // + the 16-row stage buffer of the reduction
 }
 
 int hh_conv2d_wgrad(const void *x, const void *dy, int B, int H, int W, int cin, int cout, int ks, int stride, int pad_y, int pad_x, float *dw,

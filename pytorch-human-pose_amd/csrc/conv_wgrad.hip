@@ -137,33 +137,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             }
 }
 
-// dW[co][ci][tap] = sum over workgroups (fixed order) of part[wg][tap][co][ci].  One thread = 4 consecutive ci of one
-// (tap, co): 16-byte loads, two independent accumulator sets so that eight loads are in flight per thread.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int nwg, int ntap, int cout, int cin, int coutp,
-                                                           int cinp, float *__restrict__ dw)
+// dW[co][ci][tap] = sum over workgroups (fixed order) of part[wg][tap][co][ci], in two stages so that the column sums of
+// the [workers x elements] matrix are spread over the chip: stage 1, block (x, g) adds workers g, g+G, ... for its 1024
+// consecutive elements (16-byte loads, two accumulator sets) into row g of a [G x elements] buffer placed behind the
+// partial sums; stage 2 adds the G rows and writes the OIHW gradient.
+constexpr int RG = 16;
+__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float *__restrict__ part, int nwg, size_t nel4, float *__restrict__ stage)
 {
-    const int cq = cinp / 4;
-    const size_t total = (size_t)ntap * cout * cq, stride = (size_t)ntap * coutp * cinp;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nel4) return;
+    const int g = blockIdx.y;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    int w = g;
+    for (; w + RG < nwg; w += 2 * RG) {
+        const float4 u = reinterpret_cast<const float4 *>(part)[(size_t)w * nel4 + i];
+        const float4 v = reinterpret_cast<const float4 *>(part)[(size_t)(w + RG) * nel4 + i];
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    if (w < nwg) {
+        const float4 u = reinterpret_cast<const float4 *>(part)[(size_t)w * nel4 + i];
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    }
+    reinterpret_cast<float4 *>(stage)[(size_t)g * nel4 + i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float *__restrict__ stage, int ntap, int cout, int cin, int coutp, int cinp,
+                                                            float *__restrict__ dw)
+{
+    const size_t total = (size_t)cout * cin * ntap, nel = (size_t)ntap * coutp * cinp;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c4 = (int)(i % cq) * 4;
-        const int co = (int)((i / cq) % cout), tap = (int)(i / cq / cout);
-        const float *src = part + ((size_t)tap * coutp + co) * cinp + c4;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        int w = 0;
-        for (; w + 1 < nwg; w += 2) {
-            const float4 u = *reinterpret_cast<const float4 *>(src + (size_t)w * stride);
-            const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)(w + 1) * stride);
-            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-            b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
-        }
-        if (w < nwg) {
-            const float4 u = *reinterpret_cast<const float4 *>(src + (size_t)w * stride);
-            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-        }
-        const float r[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+        const int tap = (int)(i % ntap);
+        const int ci = (int)((i / ntap) % cin), co = (int)(i / ntap / cin);
+        const size_t o = ((size_t)tap * coutp + co) * cinp + ci;
+        float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c4 + j < cin) dw[((size_t)co * cin + c4 + j) * ntap + tap] = r[j];
+        for (int g = 0; g < RG; ++g) s += stage[(size_t)g * nel + o];
+        dw[i] = s;
     }
 }
 
@@ -187,9 +196,9 @@ int conv_wgrad_num_workers(int B, int Ho, int Wo, int stride, int cin, int cout)
     const int TW = stride == 2 ? 16 : 32;
     const int ntiles = B * ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW);
     const int nblocks = ((cin + 63) / 64) * ((cout + 63) / 64);
-    int want = (HH_WGRAD_WORKERS * 4 + nblocks - 1) / nblocks;
+    int want = (HH_WGRAD_WORKERS * 2 + nblocks - 1) / nblocks;
     if (want < HH_WGRAD_WORKERS / 2) want = HH_WGRAD_WORKERS / 2;
-    if (want > HH_WGRAD_WORKERS * 4) want = HH_WGRAD_WORKERS * 4;
+    if (want > HH_WGRAD_WORKERS * 2) want = HH_WGRAD_WORKERS * 2;
     return ntiles < want ? ntiles : want;
 }
 
@@ -203,9 +212,12 @@ hipError_t conv_wgrad_launch(const WgradParams &p, int ks, int stride, float *dw
     else if (ks == 2 && stride == 1) e = launch_one<2, 1, 32>(p, nwg, s);
     if (e != hipSuccess) return e;
     const int coutp = (p.cout + 63) / 64 * 64, cinp = (p.cin + 63) / 64 * 64, ntap = ks * ks;
-    const size_t total = (size_t)ntap * p.cout * (cinp / 4);
+    const size_t nel = (size_t)ntap * coutp * cinp, nel4 = nel / 4;
+    float *stage = p.partial + (size_t)nwg * nel;
+    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((unsigned)((nel4 + 255) / 256), RG), dim3(256), 0, s, p.partial, nwg, nel4, stage);
+    const size_t total = (size_t)p.cout * p.cin * ntap;
     unsigned grid = (unsigned)((total + 255) / 256);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, p.partial, nwg, ntap, p.cout, p.cin, coutp, cinp, dw);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(grid), dim3(256), 0, s, stage, ntap, p.cout, p.cin, coutp, cinp, dw);
     return hipGetLastError();
 }
