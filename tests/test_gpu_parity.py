@@ -571,3 +571,18 @@ def test_train_step_under_distributed_data_parallel(pkg):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("C,K", [(48, 17), (32, 5)])
+def test_train_forward_backward_other_widths_and_shapes(pkg, C, K):
+    """Channel widths that are not multiples of 32 (W48), another joint count and a non-square input go through the training
+    kernels (zero-padded channel counts, 2x2 phase convs of the transposed conv): every parameter gets a finite gradient."""
+    net = pkg.HigherHRNet(K, C)
+    net.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 1)) for k, v in net.state_dict().items()})
+    net = net.to(DEV).train()
+    x = torch.from_numpy(pkg.synth.synth_images(2, 128, 192, 3)).to(DEV)
+    hms, tags = net(x)
+    assert hms[0].shape == (2, K, 32, 48) and hms[1].shape == (2, K, 64, 96) and tags.shape == (2, K, 32, 48)
+    ((hms[0] ** 2).mean() + (hms[1] ** 2).mean() + (tags ** 2).mean()).backward()
+    for n, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, n
