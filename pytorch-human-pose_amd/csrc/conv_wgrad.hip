@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     // byte offsets of this lane's transposed reads inside a tile (row part added per k-step)
     const int ycol = (tco * 32 + 16 * (g & 1) + 4 * pp) * 2, xcol = (tci * 32 + 16 * (g & 1) + 4 * pp) * 2;
 
-    // ---- staging registers: the next tile's dY tile and X patch are loaded while the current tile is multiplied; the
+    // ---- staging registers of a tile's dY tile and X patch; the
     //      zero padding (image border, channels beyond the count) is applied when the registers go to LDS, so that no
     //      load result is touched next to its issue
     u32x4 yreg[NYL], xreg[NXL];
@@ -90,8 +90,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             xmask |= ok ? (1u << i) : 0u;
         });
     };
-    issue_loads(blockIdx.x);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // (prefetching the next tile across the MFMA loop was measured: no gain, and its 44 live registers push the
+        //  pipelined loop below into scratch; two workgroups per CU cover each other's load latency instead)
+        issue_loads(t);
         __syncthreads();  // the previous tile's reads are done
         sfor<NYL>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -104,23 +106,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             if (u < X_UNITS) *reinterpret_cast<u32x4 *>(ldsX + (u >> 3) * RS + (u & 7) * 16) = (xmask >> i) & 1u ? xreg[i] : u32x4{0u, 0u, 0u, 0u};
         });
         __syncthreads();
-        issue_loads(t + gridDim.x);  // in flight during the MFMA loop below (degenerate reads of element 0 past the last tile)
         // ---- contraction over the tile's pixels, 16 per MFMA k-step (one half row of TW = 32, or a row of TW = 16)
-#pragma unroll
-        for (int y = 0; y < TH; ++y)
-#pragma unroll
-            for (int hx = 0; hx < TW / 16; ++hx) {
-                const int prow = y * TW + hx * 16 + 8 * hh + q;  // dY pixel row of this lane's first transposed read
-                const i16x4 a0 = tr_read(ldsY, prow * RS + ycol), a1 = tr_read(ldsY, (prow + 4) * RS + ycol);
-                const i16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                sfor<NTAP>([&](auto tc) {
-                    constexpr int tap = decltype(tc)::value, ky = tap / KS, kx = tap % KS;
-                    const int xrow = (y * S + ky) * PW + (hx * 16 + 8 * hh + q) * S + kx;
-                    const i16x4 b0 = tr_read(ldsX, xrow * RS + xcol), b1 = tr_read(ldsX, (xrow + 4 * S) * RS + xcol);
-                    const i16x8 bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb), acc[tap], 0, 0, 0);
-                });
-            }
+        // Flat software pipeline over (k-step, tap): the transposed reads of step i+1 are issued before the MFMA of step i
+        // (sched_group_barrier pins that order), so an MFMA never waits on the LDS latency of its own operands.
+        constexpr int NKS = TH * (TW / 16), NSTEP = NKS * NTAP;
+        i16x8 afrag[2], bfrag[2];
+        auto ld_a = [&](int ks, int buf) {
+            const int y = ks / (TW / 16), hx = ks % (TW / 16);
+            const int prow = y * TW + hx * 16 + 8 * hh + q;  // dY pixel row of this lane's first transposed read
+            const i16x4 a0 = tr_read(ldsY, prow * RS + ycol), a1 = tr_read(ldsY, (prow + 4) * RS + ycol);
+            afrag[buf] = i16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        };
+        auto ld_b = [&](int step, int buf) {
+            const int ks = step / NTAP, tap = step % NTAP, ky = tap / KS, kx = tap % KS;
+            const int y = ks / (TW / 16), hx = ks % (TW / 16);
+            const int xrow = (y * S + ky) * PW + (hx * 16 + 8 * hh + q) * S + kx;
+            const i16x4 b0 = tr_read(ldsX, xrow * RS + xcol), b1 = tr_read(ldsX, (xrow + 4 * S) * RS + xcol);
+            bfrag[buf] = i16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        };
+        ld_a(0, 0);
+        ld_b(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        sfor<NSTEP>([&](auto sc) {
+            constexpr int step = decltype(sc)::value, ks = step / NTAP, tap = step % NTAP;
+            constexpr bool next_a = step + 1 < NSTEP && (step + 1) % NTAP == 0;
+            if constexpr (step + 1 < NSTEP) ld_b(step + 1, (step + 1) & 1);
+            if constexpr (next_a) ld_a(ks + 1, (ks + 1) & 1);
+            if constexpr (step + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, next_a ? 4 : 2, 0);
+            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afrag[ks & 1]), __builtin_bit_cast(bf16x8, bfrag[step & 1]),
+                                                               acc[tap], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        });
     }
     // ---- partial sums of this workgroup: part[blockIdx.x][tap][coutp][cinp], D layout: lane = ci column, regs = co rows
     const int r32 = lane & 31, h = lane >> 5;
