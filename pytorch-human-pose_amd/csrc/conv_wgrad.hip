@@ -209,11 +209,11 @@ static hipError_t launch_one(const WgradParams &p, int nwg, hipStream_t s)
 // blocks), but no more partial-sum sets than that, since every one is 9 x 64 x 64 floats the reduction has to read back.
 int conv_wgrad_num_workers(int B, int Ho, int Wo, int stride, int cin, int cout)
 {
-    const int TW = stride == 2 ? 16 : 32;
+    const int TW = (stride == 2 || Wo <= 16) ? 16 : 32;
     const int ntiles = B * ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW);
     const int nblocks = ((cin + 63) / 64) * ((cout + 63) / 64);
     int want = (HH_WGRAD_WORKERS * 2 + nblocks - 1) / nblocks;
-    if (want < HH_WGRAD_WORKERS / 2) want = HH_WGRAD_WORKERS / 2;
+    if (want < HH_WGRAD_WORKERS / 4) want = HH_WGRAD_WORKERS / 4;  // many channel blocks already fill the chip; every worker costs a partial set
     if (want > HH_WGRAD_WORKERS * 2) want = HH_WGRAD_WORKERS * 2;
     return ntiles < want ? ntiles : want;
 }
@@ -222,7 +222,8 @@ hipError_t conv_wgrad_launch(const WgradParams &p, int ks, int stride, float *dw
 {
     const int nwg = conv_wgrad_num_workers(p.B, p.Ho, p.Wo, stride, p.cin, p.cout);
     hipError_t e = hipErrorInvalidValue;
-    if (ks == 3 && stride == 1) e = launch_one<3, 1, 32>(p, nwg, s);
+    if (ks == 3 && stride == 1 && p.Wo <= 16) e = launch_one<3, 1, 16>(p, nwg, s);  // narrow maps: no half-empty tiles
+    else if (ks == 3 && stride == 1) e = launch_one<3, 1, 32>(p, nwg, s);
     else if (ks == 1 && stride == 1) e = launch_one<1, 1, 32>(p, nwg, s);
     else if (ks == 3 && stride == 2) e = launch_one<3, 2, 16>(p, nwg, s);
     else if (ks == 2 && stride == 1) e = launch_one<2, 1, 32>(p, nwg, s);

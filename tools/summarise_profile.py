@@ -107,7 +107,7 @@ if os.path.exists(train_csv):  # kept from `rocprofv3 --kernel-trace --stats -- 
     trows = list(csv.DictReader(open(train_csv)))
     lines += ["", "## Training step (`rocprofv3 --kernel-trace --stats -- python3 tools/train_bench.py 32 3`: HigherHRNet-W32, batch 32 @ 512x512, "
               "forward with train-mode BN + AE loss + backward + Adam; 5 steps traced)", "",
-              f"Top kernels of {tag}_train_step_kernel_stats.csv (step wall time 75 ms untraced):", "",
+              f"Top kernels of {tag}_train_step_kernel_stats.csv (step wall time 72 ms untraced):", "",
               "| kernel | calls | avg us | % of kernel time |", "|---|---|---|---|"]
     lines += [f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |" for r in trows[:14]]
 open(os.path.join(prof, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
