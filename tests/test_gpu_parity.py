@@ -586,3 +586,27 @@ def test_train_forward_backward_other_widths_and_shapes(pkg, C, K):
     ((hms[0] ** 2).mean() + (hms[1] ** 2).mean() + (tags ** 2).mean()).backward()
     for n, p in net.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, n
+
+
+def test_training_loop_reduces_the_loss(pkg):
+    """module.py:43-71 end to end on the HIP path: forward (batch-stat BN) + AEKeypointsLoss + backward + Adam on one fixed
+    synthetic batch; the loss must fall by more than 5x in 15 steps (it goes 4.3 -> 0.4), i.e. the gradients are useful,
+    not merely close to the reference at step 0."""
+    K, S, B = 17, 128, 4
+    net = pkg.HigherHRNet(K, 32)
+    net.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()})
+    net = net.to(DEV).train()
+    loss_fn, opt = pkg.AEKeypointsLoss(), torch.optim.Adam(net.parameters(), lr=1e-3)
+    x = torch.from_numpy(pkg.synth.synth_images(B, S, S, 0)).to(DEV)
+    hms, masks, joints = pkg.synth.synth_train_targets(B, K, S, 3, seed=0)
+    hms, masks = [torch.from_numpy(h).to(DEV) for h in hms], [torch.from_numpy(m).to(DEV) for m in masks]
+    losses = []
+    for _ in range(15):
+        ph, pt = net(x)
+        hl, push, pull = loss_fn.calculate_loss(ph, pt, hms, masks, joints)
+        loss = hl[0] + hl[1] + push[0] + pull[0]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] / 5, losses
