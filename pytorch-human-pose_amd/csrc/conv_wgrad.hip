@@ -198,8 +198,12 @@ static hipError_t launch_one(const WgradParams &p, int nwg, hipStream_t s)
     constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
     const size_t lds = (size_t)(TH * TW + PH * PW) * RS;
     auto fn = conv_wgrad_kernel<KS, S, TW>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    static bool configured = false;  // once per instantiation
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
     const int ncob = (p.cout + 63) / 64, ncib = (p.cin + 63) / 64;
     hipLaunchKernelGGL(fn, dim3(nwg, ncob * ncib), dim3(256), lds, s, p);
     return hipGetLastError();
