@@ -197,8 +197,19 @@ int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int c
     bf16_raw *packed = (bf16_raw *)workspace;
     float *zbias = (float *)((char *)workspace + ((wel * 2 + 255) & ~(size_t)255));
     hipStream_t s = (hipStream_t)stream;
-    if (bias) HH_CHECK_HIP(hipMemcpyAsync(zbias, bias, (size_t)co * 4, hipMemcpyDeviceToDevice, s));
-    else HH_CHECK_HIP(hipMemsetAsync(zbias, 0, (size_t)coutp * 4, s));
+    // the kernel reads coutp bias values: an all-zero device array serves the bias-free case (no memset per call), a bias
+    // whose length is already a multiple of 32 is used in place, anything else is copied behind the packed weights
+    static float *zeros = nullptr;
+    if (!bias && coutp <= 4096) {
+        if (!zeros) { HH_CHECK_HIP(hipMalloc((void **)&zeros, 4096 * 4)); HH_CHECK_HIP(hipMemset(zeros, 0, 4096 * 4)); }
+        zbias = zeros;
+    } else if (!bias) {
+        HH_CHECK_HIP(hipMemsetAsync(zbias, 0, (size_t)coutp * 4, s));
+    } else if (co == coutp) {
+        zbias = const_cast<float *>(bias);
+    } else {
+        HH_CHECK_HIP(hipMemcpyAsync(zbias, bias, (size_t)co * 4, hipMemcpyDeviceToDevice, s));
+    }
     const int Ho = kstride == 2 ? H / 2 : H, Wo = kstride == 2 ? W / 2 : W;
     const int cfg = hh_pick_config(kks, kstride, KC, NT, Wo);
     if (cfg < 0) { hh_set_error("hh_conv2d: no kernel instantiation for this shape"); return 1; }
