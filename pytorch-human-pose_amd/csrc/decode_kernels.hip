@@ -702,6 +702,21 @@ __global__ __launch_bounds__(64) void refine_mean_kernel(const DecodeSrc src, in
 }
 
 // (1b) per (b,k) quarter-res cell: [lo, hi] of the 3x3 tag taps (slack included) -- shared by every person
+// bf16 roundings toward -inf / +inf (finite inputs): truncation moves toward zero, so step away from zero when bits were lost
+__device__ __forceinline__ unsigned short bf16_floor(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    unsigned short t = (unsigned short)(u >> 16);
+    if ((u & 0xffffu) && (u >> 31)) ++t;  // negative and inexact: one step more negative
+    return t;
+}
+__device__ __forceinline__ unsigned short bf16_ceil(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    unsigned short t = (unsigned short)(u >> 16);
+    if ((u & 0xffffu) && !(u >> 31)) ++t;  // positive and inexact: one step more positive
+    return t;
+}
 __global__ __launch_bounds__(256) void tag_bounds_kernel(const DecodeSrc src, float *__restrict__ tagb)
 {
     const int hq = src.H >> 2, wq = src.W >> 2, E = src.E;
@@ -718,8 +733,10 @@ __global__ __launch_bounds__(256) void tag_bounds_kernel(const DecodeSrc src, fl
                     lo = fminf(lo, t); hi = fmaxf(hi, t);
                 }
             const float slack = 1e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-30f;  // >> 3 roundings of a convex combination
-            float *o = tagb + ((((size_t)b * src.K + k) * hq * wq + c) * E + e) * 2;
-            o[0] = lo - slack; o[1] = hi + slack;
+            // stored as a bf16 pair in one dword (lo rounded DOWN, hi rounded UP: the bound only gets looser), which halves
+            // what the arg-max scans have to read per cell
+            reinterpret_cast<unsigned *>(tagb)[(((size_t)b * src.K + k) * hq * wq + c) * E + e] =
+                (unsigned)bf16_floor(lo - slack) | ((unsigned)bf16_ceil(hi + slack) << 16);
         }
     }
 }
@@ -819,12 +836,13 @@ __global__ __launch_bounds__(256) void refine_argmax_kernel(const DecodeSrc src,
                     }
             };
             // upper bound of a cell
-            const float *tb = tagb + ((size_t)b * src.K + k) * hq * wq * E * 2;
+            const unsigned *tb = reinterpret_cast<const unsigned *>(tagb) + ((size_t)b * src.K + k) * hq * wq * E;
             auto cell_ub = [&](int c) -> float {
                 float lb2 = 0.f;
                 for (int e = 0; e < E; ++e) {
-                    const float2 lh = *reinterpret_cast<const float2 *>(tb + ((size_t)c * E + e) * 2);
-                    const float d = fmaxf(fmaxf(mean[e] - lh.y, lh.x - mean[e]), 0.f);
+                    const unsigned lh = tb[(size_t)c * E + e];
+                    const float lo = __uint_as_float(lh << 16), hi = __uint_as_float(lh & 0xffff0000u);
+                    const float d = fmaxf(fmaxf(mean[e] - hi, lo - mean[e]), 0.f);
                     lb2 += d * d;
                 }
                 const float lb = __fsqrt_rn(lb2) * (1.f - 2e-6f);  // below the reference's own rounded distance
