@@ -94,6 +94,22 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v)
     return v;
 }
 
+// bf16 roundings toward -inf / +inf (finite inputs): truncation moves toward zero, so step away from zero when bits were lost
+__device__ __forceinline__ unsigned short bf16_floor(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    unsigned short t = (unsigned short)(u >> 16);
+    if ((u & 0xffffu) && (u >> 31)) ++t;  // negative and inexact: one step more negative
+    return t;
+}
+__device__ __forceinline__ unsigned short bf16_ceil(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    unsigned short t = (unsigned short)(u >> 16);
+    if ((u & 0xffffu) && !(u >> 31)) ++t;  // positive and inexact: one step more positive
+    return t;
+}
+
 // ------------------------------------------------------------------ NMS + per-tile top-M
 // grouping.py:80-83 (5x5 max-pool NMS: hm * (pool(hm) == hm)) and the first half of
 // top_k (grouping.py:147-153).  One workgroup = one 64x64 full-resolution tile of one (b,k)
@@ -183,7 +199,8 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) m = fmaxf(m, v[2 + 4 * cy + a][2 + 4 * cx + c]);
-            cellmax[(((size_t)b * src.K + k) * (src.H >> 2) + (Y >> 2)) * (src.W >> 2) + (X >> 2)] = m;
+            // kept as bf16 rounded UP: the refine kernel only needs an upper bound of the cell, and reads it for every scan
+            reinterpret_cast<unsigned short *>(cellmax)[(((size_t)b * src.K + k) * (src.H >> 2) + (Y >> 2)) * (src.W >> 2) + (X >> 2)] = bf16_ceil(m);
         }
     }
     // separable 5x5 maximum with sliding windows in registers: 16 outputs from 20 inputs (pair maxima, then pairs of
@@ -702,21 +719,6 @@ __global__ __launch_bounds__(64) void refine_mean_kernel(const DecodeSrc src, in
 }
 
 // (1b) per (b,k) quarter-res cell: [lo, hi] of the 3x3 tag taps (slack included) -- shared by every person
-// bf16 roundings toward -inf / +inf (finite inputs): truncation moves toward zero, so step away from zero when bits were lost
-__device__ __forceinline__ unsigned short bf16_floor(float f)
-{
-    const unsigned u = __float_as_uint(f);
-    unsigned short t = (unsigned short)(u >> 16);
-    if ((u & 0xffffu) && (u >> 31)) ++t;  // negative and inexact: one step more negative
-    return t;
-}
-__device__ __forceinline__ unsigned short bf16_ceil(float f)
-{
-    const unsigned u = __float_as_uint(f);
-    unsigned short t = (unsigned short)(u >> 16);
-    if ((u & 0xffffu) && !(u >> 31)) ++t;  // positive and inexact: one step more positive
-    return t;
-}
 __global__ __launch_bounds__(256) void tag_bounds_kernel(const DecodeSrc src, float *__restrict__ tagb)
 {
     const int hq = src.H >> 2, wq = src.W >> 2, E = src.E;
@@ -779,7 +781,8 @@ __global__ __launch_bounds__(256) void refine_argmax_kernel(const DecodeSrc src,
         } else {
             const int hq = src.H >> 2, wq = src.W >> 2, wh = src.W >> 1;
             const float *avg = src.avg + ((size_t)b * src.K + k) * (size_t)(src.H >> 1) * wh;
-            const float *cmax = cellmax + ((size_t)b * src.K + k) * hq * wq;
+            const unsigned short *cmaxu = reinterpret_cast<const unsigned short *>(cellmax) + ((size_t)b * src.K + k) * hq * wq;
+            auto cmax_at = [&](int c) { return __uint_as_float((unsigned)cmaxu[c] << 16); };  // bf16 upper bound of the cell maximum
             constexpr int TO[4] = {0, 0, 1, 1};  // tag source row offset (from q-1) of sub-pixel j, x4 upsampling
             constexpr float TW1[4] = {0.625f, 0.875f, 0.125f, 0.375f};
             constexpr int HO[4] = {0, 1, 1, 2};  // heat source row offset (from 2q-1), x2 upsampling
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(256) void refine_argmax_kernel(const DecodeSrc src,
                     lb2 += d * d;
                 }
                 const float lb = __fsqrt_rn(lb2) * (1.f - 2e-6f);  // below the reference's own rounded distance
-                return cmax[c] - rintf(lb);
+                return cmax_at(c) - rintf(lb);
             };
             const int ncells = hq * wq;
             float my_ub = -INFINITY;
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(256) void refine_argmax_kernel(const DecodeSrc src,
             for (int c = tid; c < ncells; c += 256) {
                 // ub(c) <= cmax[c] (the distance term is >= 0): most cells are rejected on the cell maximum alone and the
                 // tag bounds (2/3 of the bytes of a scan) are not read again
-                if (c == my_cell || cmax[c] < bound) continue;
+                if (c == my_cell || cmax_at(c) < bound) continue;
                 if (cell_ub(c) >= bound) eval_cell(c / wq, c % wq);
             }
         }
