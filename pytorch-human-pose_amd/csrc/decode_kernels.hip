@@ -123,7 +123,11 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     __shared__ float rm[HS][TS + 1];
     __shared__ float patch[PR][PR + 1];  // half-res source rows/cols of this tile (mode 0)
     __shared__ u64 wbest[2][4];
-    const int tile = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
+    // XCD-aware tile order: workgroups go to the 8 XCDs round-robin by linear block id, so with a multiple of 8 tiles per
+    // map, block x lands on XCD x % 8.  Dealing whole tile ROWS to one XCD lets horizontally adjacent tiles share the
+    // 128-byte lines their 2-pixel halos straddle in that XCD's L2 (each tile row of 36 floats touches 3 lines for 144 B).
+    const int k = blockIdx.y, b = blockIdx.z, ntile = gridDim.x;
+    const int tile = (ntile % 8 == 0) ? (blockIdx.x % 8) * (ntile / 8) + blockIdx.x / 8 : blockIdx.x;
     const int ty = tile / tiles_x, tx = tile % tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
     const int tid = threadIdx.x;
