@@ -143,7 +143,12 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fused_kernel(const BBParams p)
     const bf16_raw *pf_base = p.in;  // patch origin of the tile being prefetched
     int pf_iy0 = 0, pf_ix0 = 0;
     bool pf_more = true;  // false: there is no next tile, the loads degenerate to re-reading p.in[0..7]
-    auto pf_setup = [&](int t) {
+    // XCD-aware tile order: workgroup w (on XCD w % 8, the grid is a multiple of 8) walks tiles w, w + grid, ...; mapping tile
+    // id i to (i % 8) * (ntiles / 8) + i / 8 gives every XCD a contiguous band of tiles (whole images at 128x128), so the halo
+    // rows / straddled lines of neighbouring patches are fetched into one L2 once
+    auto band = [&](int i) { return ((p.ntiles & 7) == 0 && (gridDim.x & 7) == 0) ? (i & 7) * (p.ntiles >> 3) + (i >> 3) : i; };
+    auto pf_setup = [&](int ti) {
+        const int t = band(ti);
         const int b = t / tiles_per_img, tt = t % tiles_per_img;
         pf_iy0 = (tt / p.tiles_x) * TH - 2; pf_ix0 = (tt % p.tiles_x) * TW - 2;
         pf_base = p.in + ((ptrdiff_t)b * p.H * p.W + (ptrdiff_t)pf_iy0 * p.W + pf_ix0) * p.in_cs;
@@ -196,7 +201,8 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fused_kernel(const BBParams p)
     };
 
     for (; t < p.ntiles; t += gridDim.x) {
-        const int b = t / tiles_per_img, tt = t % tiles_per_img;
+        const int tb = band(t);
+        const int b = tb / tiles_per_img, tt = tb % tiles_per_img;
         const int oy0 = (tt / p.tiles_x) * TH, ox0 = (tt % p.tiles_x) * TW;
         const int tn = t + gridDim.x;
         pf_more = tn < p.ntiles;

@@ -87,6 +87,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
         bid = (bid & 7) | ((bid / (8 * SF)) << 3);
         if (bid >= p.B * p.tiles_y * p.tiles_x) return;  // padding of the last group (before any barrier)
     }
+    {   // ... and the tiles themselves go to the XCDs in contiguous bands (tile index low bits = XCD so far): neighbouring tiles
+        // then share the halo rows / straddled 128-byte lines of their patches in one L2 instead of fetching them once per XCD
+        const int ntiles = p.B * p.tiles_y * p.tiles_x;
+        if ((ntiles & 7) == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
+    }
     const int cg = sub % p.ncg, ph = sub / p.ncg;
     const int pad_y = nph > 1 ? ((ph >> 1) ? 0 : 1) : p.pad_y, pad_x = nph > 1 ? ((ph & 1) ? 0 : 1) : p.pad_x;
     const int ooy = nph > 1 ? (ph >> 1) : p.ooy, oox = nph > 1 ? (ph & 1) : p.oox;
