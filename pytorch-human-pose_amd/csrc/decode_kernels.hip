@@ -718,8 +718,15 @@ __global__ __launch_bounds__(64) void refine_mean_kernel(const DecodeSrc src, in
     out[HH_MAX_EMB] = (float)nt;
     if (!nt) return;
     np_mean_rows(tl, nt, E, out);
-    for (int k = 0; k < K; ++k)  // work list for the arg-max kernel: every joint of this person still missing
-        if (J[k * D + 2] == 0.f) ws_jobs[1 + atomicAdd(ws_jobs, 1)] = (b << 16) | (p << 8) | k;
+    // work lists for the arg-max kernel: every joint of this person still missing, in 8 queues by map ((b*K + k) % 8).
+    // A queue is served by the workgroups of ONE XCD, so the several people that miss the same joint of an image scan that
+    // map's cell maxima / tag bounds out of the same L2 instead of fetching them once per XCD.
+    const int cap = gridDim.x * M * K;  // queue capacity = every (b, p, k)
+    for (int k = 0; k < K; ++k)
+        if (J[k * D + 2] == 0.f) {
+            const int qx = (b * K + k) & 7;
+            ws_jobs[8 + qx * cap + atomicAdd(ws_jobs + qx, 1)] = (b << 16) | (p << 8) | k;
+        }
 }
 
 // (1b) per (b,k) quarter-res cell: [lo, hi] of the 3x3 tag taps (slack included) -- shared by every person
@@ -760,9 +767,11 @@ __global__ __launch_bounds__(256) void refine_argmax_kernel(const DecodeSrc src,
 {
     __shared__ u64 wbest[4];
     const int tid = threadIdx.x, E = src.E;
-    const int njobs = ws_jobs[0];
-    for (int job = blockIdx.x; job < njobs; job += gridDim.x) {  // persistent grid over the missing joints
-        const int code = ws_jobs[1 + job];
+    // persistent grid; workgroup x runs on XCD x % 8 (round-robin dispatch, grid a multiple of 8) and serves queue x % 8
+    const int qx = blockIdx.x & 7, cap = src.B * M * src.K;
+    const int njobs = ws_jobs[qx];
+    for (int job = blockIdx.x >> 3; job < njobs; job += gridDim.x >> 3) {
+        const int code = ws_jobs[8 + qx * cap + job];
         const int b = code >> 16, p = (code >> 8) & 0xff, k = code & 0xff;
         const float *prev = ws_prev + ((size_t)b * M + p) * (HH_MAX_EMB + 1);
         float mean[HH_MAX_EMB];
@@ -919,7 +928,7 @@ hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32
         hipLaunchKernelGGL(tag_bounds_kernel, dim3(((src.H >> 2) * (src.W >> 2) + 255) / 256, src.K, src.B), dim3(256), 0, s, src, tagb);
     hipError_t e = hipMemsetAsync(ws_best, 0, (size_t)src.B * M * src.K * sizeof(u64), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws_jobs, 0, 16, s);
+    e = hipMemsetAsync(ws_jobs, 0, 32, s);  // the 8 queue counters
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(refine_mean_kernel, dim3(src.B), dim3(64), 0, s, src, M, joints, num_people, ws_prev, ws_jobs);
     hipLaunchKernelGGL(refine_argmax_kernel, dim3(2048), dim3(256), 0, s, src, M, ws_jobs, ws_prev, cellmax, tagb, ws_best);

@@ -53,7 +53,7 @@ int hh_decoder::reserve(int B, int H, int W, int E)
     if (alloc((size_t)nB * M * (K + 1) * nE * 4, (void **)&ws_tags)) return 1;
     if (alloc((size_t)nB * M * (HH_MAX_EMB + 1) * 4, (void **)&ws_prev)) return 1;
     if (alloc((size_t)nB * M * K * 8, (void **)&ws_best)) return 1;
-    if (alloc(((size_t)nB * M * K + 4) * 4, (void **)&ws_jobs)) return 1;
+    if (alloc(((size_t)nB * M * K * 8 + 8) * 4, (void **)&ws_jobs)) return 1;  // 8 counters + 8 job queues (one per XCD)
     if (alloc(64, (void **)&status)) return 1;
     HH_CHECK_HIP(hipMemset(status, 0, 64));
     rB = nB; rH = nH; rW = nW; rE = nE;
