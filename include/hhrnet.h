@@ -195,6 +195,25 @@ int hh_bn_train_forward(const void *x, int64_t P, int C, const float *gamma, con
 int hh_bn_train_backward(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd,
                          const float *gamma, int relu, void *dx, void *dres, float *dgamma, float *dbeta, double *scratch, void *stream);
 
+/* SyncBatchNorm (src/base/model.py:42-44: `to_DDP(..., use_batchnorm=True)` converts every BatchNorm2d, the default of
+ * the reference's DDP training, trainer.py:44,253): the two passes above split around their one exchange step.
+ *   hh_bn_train_stats:          sums[2c], sums[2c+1] = sum x, sum x^2 over THIS rank's P pixels (doubles).
+ *   -- the caller all-reduces (SUM) sums and the pixel count over the ranks (RCCL) --
+ *   hh_bn_train_normalize:      mean / invstd from the global sums and count, then the same apply pass.
+ *   hh_bn_train_backward_stats: sums = sum g, sum g * xhat of this rank (g = dy after the ReLU mask); dbeta / dgamma = the
+ *                               same local sums as floats (parameter gradients are averaged by DDP like all others).
+ *   -- all-reduce (SUM) sums --
+ *   hh_bn_train_backward_apply: dx (and dres) from the global sums and count.
+ * With count == P and no exchange the results equal hh_bn_train_forward / hh_bn_train_backward.  scratch: 256*C*2 doubles. */
+int hh_bn_train_stats(const void *x, int64_t P, int C, double *sums, double *scratch, void *stream);
+int hh_bn_train_normalize(const void *x, int64_t P, int C, const double *sums, double count, const float *gamma, const float *beta, float eps,
+                          const void *res, int relu, void *y, float *mean, float *invstd, void *stream);
+int hh_bn_train_backward_stats(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd, int relu,
+                               double *sums, float *dgamma, float *dbeta, double *scratch, void *stream);
+int hh_bn_train_backward_apply(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd,
+                               const float *gamma, int relu, const double *sums, double count, void *dx, void *dres, double *scratch,
+                               void *stream);
+
 /* Multi-scale test-time augmentation (BASELINE.json configs[3]; an extension: the reference only calls its resize helper
  * with scale 1, keypoints/model.py:73): dst[B,K,H,W] (+)= weight * bilinear(src[B,K,h,w] -> HxW) with the arithmetic of
  * F.interpolate(mode="bilinear", align_corners=False); init != 0 overwrites dst.  Batch strides in elements.            */

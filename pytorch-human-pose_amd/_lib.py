@@ -77,6 +77,10 @@ def _sig(lib):
         "hh_conv2d_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
         "hh_bn_train_forward": (i32, [vp, i64, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, vp, vp]),
         "hh_bn_train_backward": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+        "hh_bn_train_stats": (i32, [vp, i64, i32, vp, vp, vp]),
+        "hh_bn_train_normalize": (i32, [vp, i64, i32, vp, dbl, vp, vp, C.c_float, vp, i32, vp, vp, vp, vp]),
+        "hh_bn_train_backward_stats": (i32, [vp, vp, vp, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
+        "hh_bn_train_backward_apply": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, dbl, vp, vp, vp, vp]),
         "hh_resize_accumulate": (i32, [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, C.c_float, i32, vp]),
         "hh_decoder_read_topk": (i32, [vp, vp, vp, vp]),
         "hh_transform_coords": (i32, [vp, i32, dbl, dbl, dbl, dbl, dbl, vp]),

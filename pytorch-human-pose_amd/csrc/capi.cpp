@@ -277,6 +277,43 @@ int hh_bn_train_backward(const void *x, const void *y, const void *dy, int64_t P
     return 0;
 }
 
+static bool bn_dims_ok(int64_t P, int C) { return P > 0 && C > 0 && C % 8 == 0 && C <= 2048; }
+
+int hh_bn_train_stats(const void *x, int64_t P, int C, double *sums, double *scratch, void *stream)
+{
+    if (!x || !sums || !scratch || !bn_dims_ok(P, C)) { hh_set_error("hh_bn_train_stats: bad argument (C must be a multiple of 8, <= 2048)"); return 1; }
+    HH_CHECK_HIP(launch_bn_train_stats((const bf16_raw *)x, C, (size_t)P, C, sums, scratch, (hipStream_t)stream));
+    return 0;
+}
+
+int hh_bn_train_normalize(const void *x, int64_t P, int C, const double *sums, double count, const float *gamma, const float *beta, float eps,
+                          const void *res, int relu, void *y, float *mean, float *invstd, void *stream)
+{
+    if (!x || !y || !sums || !gamma || !beta || !mean || !invstd || !bn_dims_ok(P, C) || !(count >= (double)P)) { hh_set_error("hh_bn_train_normalize: bad argument (count = pixels of all ranks >= P)"); return 1; }
+    HH_CHECK_HIP(launch_bn_train_normalize((const bf16_raw *)x, C, (size_t)P, C, sums, count, gamma, beta, eps, (const bf16_raw *)res, relu,
+                                           (bf16_raw *)y, mean, invstd, (hipStream_t)stream));
+    return 0;
+}
+
+int hh_bn_train_backward_stats(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd, int relu,
+                               double *sums, float *dgamma, float *dbeta, double *scratch, void *stream)
+{
+    if (!x || !y || !dy || !mean || !invstd || !sums || !dgamma || !dbeta || !scratch || !bn_dims_ok(P, C)) { hh_set_error("hh_bn_train_backward_stats: bad argument"); return 1; }
+    HH_CHECK_HIP(launch_bn_train_backward_stats((const bf16_raw *)x, (const bf16_raw *)y, (const bf16_raw *)dy, C, (size_t)P, C, mean, invstd,
+                                                relu, sums, dgamma, dbeta, scratch, (hipStream_t)stream));
+    return 0;
+}
+
+int hh_bn_train_backward_apply(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd,
+                               const float *gamma, int relu, const double *sums, double count, void *dx, void *dres, double *scratch,
+                               void *stream)
+{
+    if (!x || !y || !dy || !dx || !mean || !invstd || !gamma || !sums || !scratch || !bn_dims_ok(P, C) || !(count >= (double)P)) { hh_set_error("hh_bn_train_backward_apply: bad argument"); return 1; }
+    HH_CHECK_HIP(launch_bn_train_backward_apply((const bf16_raw *)x, (const bf16_raw *)y, (const bf16_raw *)dy, C, (size_t)P, C, mean, invstd,
+                                                gamma, relu, sums, count, (bf16_raw *)dx, (bf16_raw *)dres, scratch, (hipStream_t)stream));
+    return 0;
+}
+
 int hh_flip_images(const float *images, float *out, int B, int C, int H, int W, void *stream)
 {
     HH_CHECK_HIP(launch_flip_images(images, out, B, C, H, W, (hipStream_t)stream));

@@ -140,6 +140,16 @@ hipError_t launch_bn_train_forward(const bf16_raw *x, int cs, size_t P, int C, c
 hipError_t launch_bn_train_backward(const bf16_raw *x, const bf16_raw *y, const bf16_raw *dy, int cs, size_t P, int C, const float *mean,
                                     const float *invstd, const float *gamma, int relu, bf16_raw *dx, bf16_raw *dres, float *dgamma,
                                     float *dbeta, double *scratch, hipStream_t s);
+hipError_t launch_bn_train_stats(const bf16_raw *x, int cs, size_t P, int C, double *sums, double *scratch, hipStream_t s);
+hipError_t launch_bn_train_normalize(const bf16_raw *x, int cs, size_t P, int C, const double *sums, double count, const float *gamma,
+                                     const float *beta, float eps, const bf16_raw *res, int relu, bf16_raw *y, float *mean, float *invstd,
+                                     hipStream_t s);
+hipError_t launch_bn_train_backward_stats(const bf16_raw *x, const bf16_raw *y, const bf16_raw *dy, int cs, size_t P, int C, const float *mean,
+                                          const float *invstd, int relu, double *sums, float *dgamma, float *dbeta, double *scratch,
+                                          hipStream_t s);
+hipError_t launch_bn_train_backward_apply(const bf16_raw *x, const bf16_raw *y, const bf16_raw *dy, int cs, size_t P, int C, const float *mean,
+                                          const float *invstd, const float *gamma, int relu, const double *sums, double count, bf16_raw *dx,
+                                          bf16_raw *dres, double *scratch, hipStream_t s);
 
 // Convolution weight gradient (conv_wgrad.hip): ks in {1,3} x stride 1, and 3x3 stride 2; channels multiples of 8
 struct WgradParams {

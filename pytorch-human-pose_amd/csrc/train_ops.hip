@@ -205,12 +205,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_raw *__res
                                                            const bf16_raw *__restrict__ dy, int cs, size_t P, int C,
                                                            const float *__restrict__ mean, const float *__restrict__ invstd,
                                                            const float *__restrict__ gamma, const float *__restrict__ dgamma,
-                                                           const float *__restrict__ dbeta, int relu, bf16_raw *__restrict__ dx,
-                                                           bf16_raw *__restrict__ dres)
+                                                           const float *__restrict__ dbeta, int relu, float invP,
+                                                           bf16_raw *__restrict__ dx, bf16_raw *__restrict__ dres)
 {
     const int C8 = C / 8;
     const size_t total = P * C8;
-    const float invP = (float)(1.0 / (double)P);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t p = i / C8;
         const int g = (int)(i % C8);
@@ -250,6 +249,75 @@ hipError_t launch_bn_train_backward(const bf16_raw *x, const bf16_raw *y, const 
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, scratch, nblocks, C, dgamma, dbeta);
     unsigned grid = (unsigned)((P * (C / 8) + 255) / 256);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, dgamma, dbeta, relu, dx, dres);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, dgamma, dbeta, relu, (float)(1.0 / (double)P), dx, dres);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ SyncBatchNorm (base/model.py:42-44): the same passes,
+// split around the one exchange step.  stats -> sums[2C] doubles {sum, sum of squares} of THIS rank's pixels; the caller
+// all-reduces them (with the pixel count) over the ranks; normalize / backward_apply then use the global sums.
+__global__ __launch_bounds__(256) void bn_finalize_sums_kernel(const double *__restrict__ partial, int nblocks, int C, double *__restrict__ sums,
+                                                               float *__restrict__ fa, float *__restrict__ fb)
+{
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double a, b;
+    sum_partials_wave(partial, nblocks, C, c, a, b);
+    if (threadIdx.x & 63) return;
+    sums[2 * c] = a;
+    sums[2 * c + 1] = b;
+    if (fa) { fa[c] = (float)a; fb[c] = (float)b; }
+}
+__global__ void bn_stats_from_sums_kernel(const double *__restrict__ sums, int C, double count, float eps, float *__restrict__ mean,
+                                          float *__restrict__ invstd)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[2 * c] / count, var = sums[2 * c + 1] / count - m * m;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+}
+__global__ void bn_sums_to_f32_kernel(const double *__restrict__ sums, int C, float *__restrict__ a, float *__restrict__ b)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    a[c] = (float)sums[2 * c];
+    b[c] = (float)sums[2 * c + 1];
+}
+
+hipError_t launch_bn_train_stats(const bf16_raw *x, int cs, size_t P, int C, double *sums, double *scratch, hipStream_t s)
+{
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(HH_BN_BLOCKS), dim3(256), 0, s, x, cs, P, C, scratch);
+    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, s, scratch, HH_BN_BLOCKS, C, sums, (float *)nullptr, (float *)nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_bn_train_normalize(const bf16_raw *x, int cs, size_t P, int C, const double *sums, double count, const float *gamma,
+                                     const float *beta, float eps, const bf16_raw *res, int relu, bf16_raw *y, float *mean, float *invstd,
+                                     hipStream_t s)
+{
+    hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, count, eps, mean, invstd);
+    unsigned grid = (unsigned)((P * (C / 8) + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, s, x, cs, P, C, mean, invstd, gamma, beta, res, relu, y);
+    return hipGetLastError();
+}
+hipError_t launch_bn_train_backward_stats(const bf16_raw *x, const bf16_raw *y, const bf16_raw *dy, int cs, size_t P, int C, const float *mean,
+                                          const float *invstd, int relu, double *sums, float *dgamma, float *dbeta, double *scratch,
+                                          hipStream_t s)
+{
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(HH_BN_BLOCKS), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, relu, scratch);
+    // this rank's sums are also its dbeta / dgamma (the parameter gradients are averaged by DDP like every other one)
+    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, s, scratch, HH_BN_BLOCKS, C, sums, dbeta, dgamma);
+    return hipGetLastError();
+}
+hipError_t launch_bn_train_backward_apply(const bf16_raw *x, const bf16_raw *y, const bf16_raw *dy, int cs, size_t P, int C, const float *mean,
+                                          const float *invstd, const float *gamma, int relu, const double *sums, double count, bf16_raw *dx,
+                                          bf16_raw *dres, double *scratch, hipStream_t s)
+{
+    float *ga = reinterpret_cast<float *>(scratch), *gb = ga + C;  // global sum g, sum g * xhat as floats
+    hipLaunchKernelGGL(bn_sums_to_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, ga, gb);
+    unsigned grid = (unsigned)((P * (C / 8) + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, gb, ga, relu, (float)(1.0 / count), dx, dres);
     return hipGetLastError();
 }

@@ -31,6 +31,103 @@ def parse_checkpoint(ckpt: dict) -> dict:
     return out
 
 
+class KeypointsModel:
+    """Training-side model wrapper: `KeypointsModel` (keypoints/model.py:15-40) on `BaseModel` (base/model.py:15-131)
+    without the export / summary helpers (onnx, torchinfo: out of scope)."""
+
+    def __init__(self, net: nn.Module):
+        self.net = net
+        self.input_names, self.output_names = ["images"], ["keypoints"]
+
+    def _bare(self) -> nn.Module:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        return self.net.module if isinstance(self.net, DDP) else self.net
+
+    def forward(self, images: Tensor):
+        return self.net(images)
+
+    def init_weights(self) -> None:
+        """keypoints/model.py:19-34: conv / transposed-conv weights ~ N(0, 0.001), their biases 0, BatchNorm weight 1 / bias 0."""
+        net = self._bare()
+        for m in net.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.normal_(m.weight, std=0.001)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        net.mark_dirty()
+
+    def init_pretrained_weights(self, ckpt: dict) -> None:
+        """base/model.py:101-123: load the checkpoint entries whose names exist here, ignore the rest."""
+        net = self._bare()
+        names = {n for n, _ in net.named_parameters()} | {n for n, _ in net.named_buffers()}
+        net.load_state_dict({k: v for k, v in parse_checkpoint(ckpt).items() if k in names}, strict=False)
+
+    def to_CUDA(self, device_id: int) -> None:
+        self.net = self.net.cuda(device_id)
+
+    def to_DDP(self, device_id: int, use_batchnorm: bool) -> None:
+        """base/model.py:36-48.  `use_batchnorm` is the reference's SyncBatchNorm switch (its trainer's default): here the
+        BatchNorm leaves stay what they are and the training forward shares their statistics across the ranks of the default
+        process group (hh_bn_train_stats -> all-reduce -> hh_bn_train_normalize).  Gradients: torch DDP's bucketed
+        all-reduce on RCCL, overlapped with the backward."""
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        self.net.sync_batchnorm = True if use_batchnorm else None
+        self.net = DDP(self.net, device_ids=[device_id])
+
+    @property
+    def device(self):
+        return next(self._bare().parameters()).device
+
+    def freeze(self) -> None:
+        for p in self.net.parameters():
+            p.requires_grad = False
+
+    def state_dict(self) -> dict:
+        return self._bare().state_dict()
+
+    def load_state_dict(self, state_dict: dict) -> None:
+        self._bare().load_state_dict(state_dict)
+
+    def example_input(self) -> dict[str, Tensor]:
+        return {"images": torch.randn(1, 3, 512, 512, device=self.device)}
+
+
+class KeypointsModule:
+    """`KeypointsModule.training_step` (keypoints/module.py:43-71): forward, AE loss, backward, optimizer step.  The reference
+    runs under fp16 autocast with a GradScaler; this path keeps activations in bf16 (no scaler needed) and parameters fp32."""
+
+    def __init__(self, model: KeypointsModel, loss_fn, optimizer: torch.optim.Optimizer):
+        self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
+
+    def batch_to_device(self, batch):
+        images, heatmaps, masks, joints = batch
+        dev = self.model.device
+        return images.to(dev), [h.to(dev, non_blocking=True) for h in heatmaps], [m.to(dev, non_blocking=True) for m in masks], joints
+
+    def training_step(self, batch, batch_idx: int = 0) -> dict[str, float]:
+        images, heatmaps, masks, joints = batch
+        stages_hms, tags = self.model.net(images)
+        hm_losses, push_losses, pull_losses = self.loss_fn.calculate_loss(stages_hms, tags, heatmaps, masks, joints)
+        loss = 0
+        for hl in hm_losses:
+            loss = loss + hl
+        loss = loss + push_losses[0] + pull_losses[0]
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        self.model._bare().mark_dirty()
+        metrics = {"loss": loss.detach().item()}
+        for i, hl in enumerate(hm_losses):
+            metrics[f"hm_{i}_loss"] = hl.item()
+        for i in range(len(push_losses)):
+            metrics[f"push_{i}_loss"] = push_losses[i].item()
+            metrics[f"pull_{i}_loss"] = pull_losses[i].item()
+        return metrics
+
+
 class InferenceKeypointsModel:
     limbs = COCO_LIMBS
 

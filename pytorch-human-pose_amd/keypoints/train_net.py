@@ -36,15 +36,24 @@ class _ConvFn(torch.autograd.Function):
 class _BNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, res, relu: bool, eps: float, stats: list):
-        y, mean, invstd = ops.bn_train_forward(x, gamma, beta, eps, res, relu)
+        ctx.sync = _sync_world()
+        if ctx.sync is not None:  # SyncBatchNorm: statistics over every rank's pixels
+            y, mean, invstd, ctx.count = ops.sync_bn_train_forward(x, gamma, beta, eps, res, relu, *ctx.sync)
+        else:
+            y, mean, invstd = ops.bn_train_forward(x, gamma, beta, eps, res, relu)
+            ctx.count = x.shape[0] * x.shape[2] * x.shape[3]
         ctx.save_for_backward(x, y, mean, invstd, gamma)
         ctx.relu, ctx.has_res = relu, res is not None
-        stats.append((mean, invstd))
+        stats.append((mean, invstd, ctx.count))
         return y
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         x, y, mean, invstd, gamma = ctx.saved_tensors
+        if ctx.sync is not None:
+            dx, dgamma, dbeta, dres = ops.sync_bn_train_backward(x, y, dy.contiguous(memory_format=torch.channels_last), mean, invstd,
+                                                                 gamma, ctx.relu, ctx.has_res, ctx.sync[0], ctx.count)
+            return dx, dgamma, dbeta, dres, None, None, None
         dx, dgamma, dbeta, dres = ops.bn_train_backward(x, y, dy.contiguous(memory_format=torch.channels_last), mean, invstd, gamma,
                                                         ctx.relu, want_dres=ctx.has_res)
         return dx, dgamma, dbeta, dres, None, None, None
@@ -73,6 +82,20 @@ def conv(x: Tensor, m: nn.Conv2d, stride: int | None = None) -> Tensor:
     return y
 
 
+_SYNC: list = [None]  # process group of the forward in flight when the net was converted to SyncBatchNorm (else None)
+
+
+def _sync_world():
+    """(group, world_size) when BatchNorm statistics are shared across ranks: like torch's SyncBatchNorm, only if a process
+    group with more than one rank exists; otherwise None (plain BatchNorm)."""
+    import torch.distributed as dist
+    if _SYNC[0] is None or not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = None if _SYNC[0] is True else _SYNC[0]
+    world = dist.get_world_size(group)
+    return (group, world) if world > 1 else None
+
+
 _PENDING_STATS: list = []  # (module, batch mean, batch invstd, pixels) of the forward in flight, applied by flush_running_stats
 
 
@@ -83,7 +106,7 @@ def bn(x: Tensor, m: nn.BatchNorm2d, relu: bool = False, res: Tensor | None = No
     y = _BNFn.apply(x.contiguous(memory_format=torch.channels_last), m.weight, m.bias,
                     res.contiguous(memory_format=torch.channels_last) if res is not None else None, relu, m.eps, stats)
     if m.track_running_stats and m.running_mean is not None:
-        _PENDING_STATS.append((m, stats[0][0], stats[0][1], x.shape[0] * x.shape[2] * x.shape[3]))
+        _PENDING_STATS.append((m, stats[0][0], stats[0][1], stats[0][2]))  # count = pixels of all ranks under SyncBatchNorm
     return y
 
 
@@ -180,6 +203,7 @@ def higher_hrnet_train_forward(net, images: Tensor):
     K = net.num_kpts
     bb = net.backbone
     _PENDING_STATS.clear()
+    _SYNC[0] = getattr(net, "sync_batchnorm", None)  # set by KeypointsModel.to_DDP(..., use_batchnorm=True)
     x = images.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     x = bn(conv(x, bb.conv1), bb.bn1, relu=True)
     x = bn(conv(x, bb.conv2), bb.bn2, relu=True)

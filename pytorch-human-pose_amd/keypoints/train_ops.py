@@ -89,6 +89,61 @@ def bn_train_backward(x: Tensor, y: Tensor, dy: Tensor, mean: Tensor, invstd: Te
     return dx, dgamma, dbeta, dres
 
 
+def _all_reduce_sums(sums: Tensor, group) -> None:
+    import torch.distributed as dist
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)  # RCCL on the GPU box; 2C doubles per layer
+
+
+def sync_bn_train_forward(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, res: Tensor | None, relu: bool, group, world: int):
+    """SyncBatchNorm forward (base/model.py:42-44): statistics over the pixels of ALL ranks of `group`.  Every rank must hold
+    the same number of pixels (DistributedSampler with drop_last=True, datamodule.py:68-89).  -> (y, mean, invstd, count)"""
+    lib = _lib.load()
+    x = _nhwc(x)
+    B, C, H, W = x.shape
+    P = B * H * W
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+    sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+    scratch = torch.empty(256 * C * 2, device=x.device, dtype=torch.float64)
+    if res is not None:
+        res = _nhwc(res)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    with torch.cuda.device(x.device):
+        _lib.check(lib.hh_bn_train_stats(x.data_ptr(), P, C, sums.data_ptr(), scratch.data_ptr(), stream))
+        _all_reduce_sums(sums, group)
+        count = float(P) * world
+        _lib.check(lib.hh_bn_train_normalize(x.data_ptr(), P, C, sums.data_ptr(), count, gamma.float().contiguous().data_ptr(),
+                                             beta.float().contiguous().data_ptr(), eps, res.data_ptr() if res is not None else None,
+                                             int(relu), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), stream))
+    return y, mean, invstd, count
+
+
+def sync_bn_train_backward(x: Tensor, y: Tensor, dy: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, relu: bool, want_dres: bool,
+                           group, count: float):
+    """-> (dx, dgamma, dbeta, dres or None); dgamma / dbeta are this rank's sums (DDP averages parameter gradients)."""
+    lib = _lib.load()
+    x, y, dy = _nhwc(x), _nhwc(y), _nhwc(dy)
+    B, C, H, W = x.shape
+    P = B * H * W
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+    sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+    scratch = torch.empty(256 * C * 2, device=x.device, dtype=torch.float64)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    g = gamma.float().contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.hh_bn_train_backward_stats(x.data_ptr(), y.data_ptr(), dy.data_ptr(), P, C, mean.data_ptr(), invstd.data_ptr(),
+                                                  int(relu), sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(), stream))
+        _all_reduce_sums(sums, group)
+        _lib.check(lib.hh_bn_train_backward_apply(x.data_ptr(), y.data_ptr(), dy.data_ptr(), P, C, mean.data_ptr(), invstd.data_ptr(),
+                                                  g.data_ptr(), int(relu), sums.data_ptr(), count, dx.data_ptr(),
+                                                  dres.data_ptr() if dres is not None else None, scratch.data_ptr(), stream))
+    return dx, dgamma, dbeta, dres
+
+
 def conv2d_weight_grad(x: Tensor, dy: Tensor, ks: int, stride: int = 1, pad: tuple[int, int] | None = None) -> Tensor:
     """dL/dW [cout,cin,ks,ks] fp32 of y = conv(x, W) (padding (ks-1)/2) from the layer input x and dL/dy."""
     lib = _lib.load()

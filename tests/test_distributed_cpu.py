@@ -39,6 +39,47 @@ def test_shard_and_gather_two_ranks(n_items):
     assert got == list(range(n_items))
 
 
+def _syncbn_worker(rank, world, port, q):
+    """The exchange step of SyncBatchNorm as the training forward runs it (train_net._sync_world, train_ops._all_reduce_sums):
+    per-rank {sum, sum of squares} doubles -> all-reduce -> the full-batch mean / biased variance on every rank."""
+    import numpy as np, torch
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    tn = importlib.import_module(PKG + ".keypoints.train_net")
+    ops = importlib.import_module(PKG + ".keypoints.train_ops")
+    tn._SYNC[0] = True
+    before = tn._sync_world()          # no process group yet: plain BatchNorm, like torch's SyncBatchNorm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    with_group = tn._sync_world()
+    tn._SYNC[0] = None
+    unset = tn._sync_world()
+    x = np.random.default_rng(5).normal(0.3, 2.0, (4, 6, 5, 8))  # [B, C, H, W], the same on both ranks
+    mine = x[rank * 2:(rank + 1) * 2]
+    sums = torch.from_numpy(np.stack([mine.sum((0, 2, 3)), (mine ** 2).sum((0, 2, 3))], 1).reshape(-1).copy())
+    ops._all_reduce_sums(sums, None)
+    count = mine[:, 0].size * world
+    s = sums.numpy().reshape(-1, 2)
+    mean, var = s[:, 0] / count, s[:, 1] / count - (s[:, 0] / count) ** 2
+    q.put((rank, before is None, with_group == (None, world), unset is None,
+           bool(np.allclose(mean, x.mean((0, 2, 3)), rtol=1e-12, atol=1e-12) and np.allclose(var, x.var((0, 2, 3)), rtol=1e-10, atol=1e-12))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_exchange_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 77) % 2000
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got == [(0, True, True, True, True), (1, True, True, True, True)]
+
+
 def test_shard_range_partitions():
     d = importlib.import_module(PKG + ".keypoints.distributed")
     for n in (0, 1, 5, 8, 5000):

@@ -187,3 +187,34 @@ def test_multi_lane_schedule_has_no_unordered_hazard(pkg):
     lib = pkg._lib.load()
     for net in (pkg.HigherHRNet(17, 32), pkg.HigherHRNet(17, 48), pkg.HigherHRNet(5, 32), pkg.ClassificationHRNet(32, 10)):
         assert lib.hh_debug_check_plan(net._h) == 0, lib.hh_last_error().decode()
+
+
+def test_keypoints_model_init_weights_and_wrappers():
+    """KeypointsModel.init_weights (keypoints/model.py:19-34): conv / transposed-conv weights ~ N(0, 0.001) with zero bias,
+    BatchNorm weight 1 / bias 0; init_pretrained_weights keeps the names that exist and drops the rest (base/model.py:101-123)."""
+    import torch
+    from torch import nn
+    pkg = importlib.import_module(PKG)
+    KeypointsModel = importlib.import_module(PKG + ".keypoints.model").KeypointsModel
+    net = pkg.HigherHRNet(17, 32)
+    model = KeypointsModel(net)
+    torch.manual_seed(0)
+    model.init_weights()
+    n_conv = 0
+    for m in net.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            n_conv += 1
+            if m.weight.numel() > 4000:
+                assert abs(m.weight.std().item() - 1e-3) < 1.5e-4 and abs(m.weight.mean().item()) < 1e-4
+            assert m.bias is None or (m.bias == 0).all()
+        elif isinstance(m, nn.BatchNorm2d):
+            assert (m.weight == 1).all() and (m.bias == 0).all()
+    assert n_conv == 303 and net._dirty  # 302 convs + the transposed conv
+    sd = {("module.net." + k): (v + 1 if v.dtype.is_floating_point else v) for k, v in list(net.state_dict().items())[:7]}
+    sd["module.net.not_a_layer.weight"] = torch.zeros(3)
+    first = next(iter(net.state_dict().values())).clone()
+    model.init_pretrained_weights(sd)
+    assert torch.equal(next(iter(net.state_dict().values())), first + 1)
+    assert set(model.state_dict()) == set(net.state_dict()) and model.device.type == "cpu"
+    model.freeze()
+    assert not any(p.requires_grad for p in net.parameters())
