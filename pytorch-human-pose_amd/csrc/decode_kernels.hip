@@ -411,9 +411,11 @@ __device__ void np_mean_rows(const float *rows, int n, int E, float *out)
 }
 
 // ------------------------------------------------------------------ match_by_tag
-// grouping.py:85-145 with munkres 1.1.4 (munkres.py:114-340) restated wave-parallel: one
-// wave per image, cost matrix in LDS (float64), column j on lane j.  Only operations whose
-// result is order-independent are spread over lanes; the rest runs on lane 0.
+// grouping.py:85-145 with munkres 1.1.4 (munkres.py:114-340) restated wave-parallel: one wave per image.  The cost matrix
+// (float64) is built in LDS, then column j lives in the registers of lane j; the zero pattern of row i is a 64-bit mask on
+// lane i, covers are two wave-uniform masks and the star / prime of row i are two ints on lane i, so the search steps
+// (munkres steps 2-5) are bit operations and lane reads - no memory, no barrier.  Every decision (which uncovered zero is
+// taken first, the path of step 5) is the one munkres.py takes.
 #define MLD 33
 struct MatchShared {
     double Cm[HH_MAX_PEOPLE * MLD];
@@ -424,115 +426,116 @@ struct MatchShared {
     float gkey[HH_MAX_PEOPLE];
     int gnt[HH_MAX_PEOPLE];
     int assign[HH_MAX_PEOPLE];
-    int path[4 * HH_MAX_PEOPLE + 4];
-    unsigned char marked[HH_MAX_PEOPLE * MLD];
-    unsigned char rc[HH_MAX_PEOPLE], cc[HH_MAX_PEOPLE];
     int G;
 };
 
-__device__ int munkres_wave(MatchShared &S, int n, int lane)
+__device__ __forceinline__ u64 readlane_u64(u64 v, int l)
 {
-    // step 1
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+// -> 0 and `star` = the starred column of row `lane` (-1: none), or 1 if the iteration guard ran out
+__device__ int munkres_wave(MatchShared &S, int n, int lane, int &star)
+{
+    // step 1: subtract the row minimum (lane = row, on the LDS copy)
     if (lane < n) {
         double mn = S.Cm[lane * MLD];
         for (int j = 1; j < n; ++j) { const double c = S.Cm[lane * MLD + j]; if (c < mn) mn = c; }
         for (int j = 0; j < n; ++j) S.Cm[lane * MLD + j] -= mn;
     }
-    for (int i = lane; i < n * MLD; i += 64) S.marked[i] = 0;
-    if (lane < n) { S.rc[lane] = 0; S.cc[lane] = 0; }
     __syncthreads();
-    // step 2
-    if (lane == 0) {
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j)
-                if (S.Cm[i * MLD + j] == 0 && !S.cc[j] && !S.rc[i]) { S.marked[i * MLD + j] = 1; S.cc[j] = 1; S.rc[i] = 1; break; }
-        for (int i = 0; i < n; ++i) { S.rc[i] = 0; S.cc[i] = 0; }
+    double col[HH_MAX_PEOPLE];  // column `lane`
+    u64 myz = 0;                // zeros of row `lane`
+#pragma unroll
+    for (int i = 0; i < HH_MAX_PEOPLE; ++i) {
+        col[i] = 1.0;
+        if (i < n) {
+            if (lane < n) col[i] = S.Cm[i * MLD + lane];
+            const u64 m = __ballot(lane < n && col[i] == 0.0);
+            if (lane == i) myz = m;
+        }
     }
-    __syncthreads();
+    int starcol = -1, primecol = -1;  // of row `lane`
+    u64 ccm = 0, rcm = 0;             // covered columns / rows
+    // step 2: star the first zero of each row whose column has no star yet
+    for (int i = 0; i < n; ++i) {
+        const u64 z = readlane_u64(myz, i) & ~ccm;
+        if (z) {
+            const int j = __builtin_ctzll(z);
+            if (lane == i) starcol = j;
+            ccm |= 1ull << j;
+        }
+    }
+    ccm = 0;
     int step = 3, z0r = 0, z0c = 0;
     for (int guard = 0; guard < 200000; ++guard) {
-        if (step == 3) {
-            bool star = false;
-            if (lane < n)
-                for (int i = 0; i < n; ++i) star |= (S.marked[i * MLD + lane] == 1);
-            if (lane < n && star) S.cc[lane] = 1;
-            const int count = __popcll(__ballot(star));
-            __syncthreads();
-            if (count >= n) return 0;
+        if (step == 3) {  // cover every column that holds a star
+            u64 rows = __ballot(starcol >= 0);
+            while (rows) {
+                const int i = __builtin_ctzll(rows);
+                rows &= rows - 1;
+                ccm |= 1ull << __builtin_amdgcn_readlane(starcol, i);
+            }
+            if (__popcll(ccm) >= n) { star = starcol; return 0; }
             step = 4;
         } else if (step == 4) {
-            int row = 0, col = 0;
+            int row = 0, colc = 0;
             for (;;) {
-                int fr = -1, fc = -1;
-                for (int t = 0; t < n; ++t) {
-                    const int i = (row + t) % n;
-                    if (S.rc[i]) continue;
-                    const bool z = lane < n && S.Cm[i * MLD + lane] == 0 && !S.cc[lane];
-                    const u64 mask = __ballot(z);
-                    if (mask) {  // last uncovered zero in cyclic column order starting at `col`
-                        const u64 low = mask & ((1ull << col) - 1ull);
-                        fc = 63 - __builtin_clzll(low ? low : mask);
-                        fr = i;
-                        break;
-                    }
-                }
-                if (fr < 0) { step = 6; break; }
-                const u64 smask = __ballot(lane < n && S.marked[fr * MLD + lane] == 1);
-                __syncthreads();
-                if (lane == 0) S.marked[fr * MLD + fc] = 2;
-                if (smask) {
-                    const int sc = __builtin_ctzll(smask);
-                    if (lane == 0) { S.rc[fr] = 1; S.cc[sc] = 0; }
-                    row = fr; col = sc;
-                    __syncthreads();
+                // first uncovered row (cyclic from `row`) with an uncovered zero; in it the last uncovered zero in cyclic
+                // column order starting at `colc`
+                const u64 rows = __ballot(lane < n && !((rcm >> lane) & 1) && (myz & ~ccm) != 0);
+                if (!rows) { step = 6; break; }
+                const u64 hi = rows & ~((1ull << row) - 1ull);
+                const int fr = __builtin_ctzll(hi ? hi : rows);
+                const u64 unc = readlane_u64(myz, fr) & ~ccm;
+                const u64 low = unc & ((1ull << colc) - 1ull);
+                const int fc = 63 - __builtin_clzll(low ? low : unc);
+                if (lane == fr) primecol = fc;
+                const int sc = __builtin_amdgcn_readlane(starcol, fr);
+                if (sc >= 0) {
+                    rcm |= 1ull << fr;
+                    ccm &= ~(1ull << sc);
+                    row = fr; colc = sc;
                 } else {
                     z0r = fr; z0c = fc; step = 5;
-                    __syncthreads();
                     break;
                 }
             }
-        } else if (step == 5) {
-            if (lane == 0) {
-                int count = 0;
-                S.path[0] = z0r; S.path[1] = z0c;
-                for (;;) {
-                    int r = -1;
-                    for (int i = 0; i < n; ++i) if (S.marked[i * MLD + S.path[count * 2 + 1]] == 1) { r = i; break; }
-                    if (r < 0) break;
-                    ++count; S.path[count * 2] = r; S.path[count * 2 + 1] = S.path[(count - 1) * 2 + 1];
-                    int c = -1;
-                    for (int j = 0; j < n; ++j) if (S.marked[S.path[count * 2] * MLD + j] == 2) { c = j; break; }
-                    ++count; S.path[count * 2] = S.path[(count - 1) * 2]; S.path[count * 2 + 1] = c;
-                }
-                for (int i = 0; i <= count; ++i) {
-                    unsigned char *m = &S.marked[S.path[i * 2] * MLD + S.path[i * 2 + 1]];
-                    *m = (*m == 1) ? 0 : 1;
-                }
-                for (int i = 0; i < n; ++i) { S.rc[i] = 0; S.cc[i] = 0; }
+        } else if (step == 5) {  // alternate primes and stars from the uncovered prime: each row on the path takes its prime
+            const int oldstar = starcol;
+            int r = z0r, c = z0c;
+            for (int hop = 0; hop <= HH_MAX_PEOPLE; ++hop) {
+                const u64 sm = __ballot(oldstar == c);  // the star of column c before the flips
+                if (lane == r) starcol = c;
+                if (!sm) break;
+                r = __builtin_ctzll(sm);
+                c = __builtin_amdgcn_readlane(primecol, r);
             }
-            __syncthreads();
-            if (lane < n)
-                for (int i = 0; i < n; ++i) if (S.marked[i * MLD + lane] == 2) S.marked[i * MLD + lane] = 0;
-            __syncthreads();
+            rcm = 0; ccm = 0; primecol = -1;
             step = 3;
-        } else {  // step 6
+        } else {  // step 6: smallest uncovered value; add it to covered rows, subtract it from uncovered columns
             double mn = 9223372036854775807.0;
-            if (lane < n && !S.cc[lane])
-                for (int i = 0; i < n; ++i)
-                    if (!S.rc[i] && mn > S.Cm[i * MLD + lane]) mn = S.Cm[i * MLD + lane];
+            const bool cu = lane < n && !((ccm >> lane) & 1);
+#pragma unroll
+            for (int i = 0; i < HH_MAX_PEOPLE; ++i)
+                if (i < n && cu && !((rcm >> i) & 1) && mn > col[i]) mn = col[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 const double o = __shfl_xor(mn, off);
                 mn = o < mn ? o : mn;
             }
-            if (lane < n)
-                for (int i = 0; i < n; ++i) {
-                    double c = S.Cm[i * MLD + lane];
-                    if (S.rc[i]) c += mn;
-                    if (!S.cc[lane]) c -= mn;
-                    S.Cm[i * MLD + lane] = c;
+#pragma unroll
+            for (int i = 0; i < HH_MAX_PEOPLE; ++i)
+                if (i < n) {
+                    double c = col[i];
+                    if ((rcm >> i) & 1) c += mn;
+                    if (!((ccm >> lane) & 1)) c -= mn;
+                    col[i] = c;
+                    const u64 m = __ballot(lane < n && c == 0.0);
+                    if (lane == i) myz = m;
                 }
-            __syncthreads();
             step = 4;
         }
     }
@@ -600,12 +603,9 @@ __global__ __launch_bounds__(64) void match_kernel(const float *__restrict__ tag
                 S.Cm[a * MLD + g] = c;
             }
             __syncthreads();
-            bad |= munkres_wave(S, n, lane);
-            if (lane < na) {
-                int col = -1;
-                for (int j = 0; j < n; ++j) if (S.marked[lane * MLD + j] == 1) { col = j; break; }
-                S.assign[lane] = col;
-            }
+            int star = -1;
+            bad |= munkres_wave(S, n, lane, star);
+            if (lane < na) S.assign[lane] = star;
             __syncthreads();
         }
         if (lane == 0) {  // dict semantics of grouping.py:104-143, candidates in row order
