@@ -544,16 +544,26 @@ __device__ int munkres_wave(MatchShared &S, int n, int lane, int &star)
 
 __constant__ int c_joints_order[17] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 7, 8, 9, 10, 13, 14, 15, 16};  // grouping.py:63-65
 
-__global__ __launch_bounds__(64) void match_kernel(const float *__restrict__ tags_k, const int32_t *__restrict__ coords_k,
-                                                   const float *__restrict__ scores_k, int K, int M, int E, double det_thr,
+__global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const int32_t *coords_k, const float *scores_k, int K, int M, int E,
+                                                   double det_thr,
                                                    double tag_thr, float *__restrict__ joints, int32_t *__restrict__ num_people,
-                                                   float *__restrict__ ws_tags, int32_t *__restrict__ status)
+                                                   float *__restrict__ ws_tags, int32_t *__restrict__ status, int stage)
 {
     __shared__ MatchShared S;
+    extern __shared__ float staged[];  // the image's candidates and group tag lists, when they fit (stage != 0)
     const int b = blockIdx.x, lane = threadIdx.x, D = 3 + E;
     float *J = joints + (size_t)b * M * K * D;
     float *GT = ws_tags + (size_t)b * M * (K + 1) * E;  // per group: list of member tags
     tags_k += (size_t)b * K * M * E; coords_k += (size_t)b * K * M * 2; scores_k += (size_t)b * K * M;
+    if (stage) {  // one coalesced read instead of a dependent global round trip per joint
+        float *st = staged, *ss = st + K * M * E;
+        int32_t *sc = reinterpret_cast<int32_t *>(ss + K * M);
+        for (int i = lane; i < K * M * E; i += 64) st[i] = tags_k[i];
+        for (int i = lane; i < K * M; i += 64) ss[i] = scores_k[i];
+        for (int i = lane; i < K * M * 2; i += 64) sc[i] = coords_k[i];
+        tags_k = st; scores_k = ss; coords_k = sc;
+        GT = reinterpret_cast<float *>(sc + K * M * 2);
+    }
     for (int i = lane; i < M * K * D; i += 64) J[i] = 0.f;
     if (lane == 0) S.G = 0;
     __syncthreads();
@@ -660,8 +670,10 @@ hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const floa
                         double det_thr, double tag_thr, float *joints, int32_t *num_people, float *ws_tags, int32_t *status,
                         hipStream_t s)
 {
-    hipLaunchKernelGGL(match_kernel, dim3(B), dim3(64), 0, s, tags_k, coords_k, scores_k, K, M, E, det_thr, tag_thr, joints,
-                       num_people, ws_tags, status);
+    const size_t bytes = ((size_t)K * M * (E + 3) + (size_t)M * (K + 1) * E) * 4;  // candidates + group tag lists
+    const int stage = bytes <= 40 * 1024;
+    hipLaunchKernelGGL(match_kernel, dim3(B), dim3(64), stage ? bytes : 0, s, tags_k, coords_k, scores_k, K, M, E, det_thr, tag_thr,
+                       joints, num_people, ws_tags, status, stage);
     return hipGetLastError();
 }
 
