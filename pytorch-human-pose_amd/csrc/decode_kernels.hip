@@ -218,8 +218,8 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
 #pragma unroll
         for (int i = 0; i < 16; ++i) out[i] = fmaxf(p4[i], in[i + 4]);
     };
-    for (int it = tid; it < HS * (TS / 16); it += 256) {  // rows: 68 x 4 strips of 16 outputs
-        const int ly = it / (TS / 16), lx0 = (it % (TS / 16)) * 16;
+    {  // rows 0..63: 64 x 4 strips of 16 outputs, one per thread
+        const int ly = tid / (TS / 16), lx0 = (tid % (TS / 16)) * 16;
         float in[20], out[16];
 #pragma unroll
         for (int i = 0; i < 20; ++i) in[i] = v[ly][lx0 + i];
@@ -227,10 +227,16 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
 #pragma unroll
         for (int i = 0; i < 16; ++i) rm[ly][lx0 + i] = out[i];
     }
+    {  // rows 64..67: one output per thread (a second strip pass would idle 15 of 16 threads)
+        const int ly = TS + tid / TS, lx = tid % TS;
+        rm[ly][lx] = fmaxf(fmaxf(fmaxf(v[ly][lx], v[ly][lx + 1]), fmaxf(v[ly][lx + 2], v[ly][lx + 3])), v[ly][lx + 4]);
+    }
     __syncthreads();
-    u64 keys[16];
     float vals[16];
     const int mpx = tid % TS, mpy0 = (tid / TS) * 16;  // this thread's pixels: column mpx, rows mpy0 .. mpy0+15
+    const int nin = (x0 + mpx < src.W) ? min(16, src.H - (y0 + mpy0)) : 0;  // its first `nin` pixels are inside the image
+    // the sort key of pixel j; only built for the few pixels that need one (positive peaks, the rare generic rounds)
+    auto key_of = [&](int j) { return make_key(vals[j], (unsigned)((y0 + mpy0 + j) * src.W + x0 + mpx)); };
     {
         float in[20], out[16];
 #pragma unroll
@@ -239,9 +245,7 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float c = v[mpy0 + j + 2][mpx + 2];
-            const int Y = y0 + mpy0 + j, X = x0 + mpx;
             vals[j] = c * ((out[j] == c) ? 1.0f : 0.0f);
-            keys[j] = (Y < src.H && X < src.W) ? make_key(vals[j], (unsigned)(Y * src.W + X)) : 0ull;
         }
     }
     const size_t obase = ((((size_t)b * src.K + k) * gridDim.x) + tile) * M;
@@ -254,13 +258,13 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     __syncthreads();           // everyone is done reading rm
     if (tid == 0) { ccount = 0; nfilled = 0; }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) nv[mpy0 + j][mpx] = keys[j] ? vals[j] : __builtin_nanf("");  // NaN = outside the image
+    for (int j = 0; j < 16; ++j) nv[mpy0 + j][mpx] = j < nin ? vals[j] : __builtin_nanf("");  // NaN = outside the image
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-        if (keys[j] && vals[j] > 0.f) {
+        if (j < nin && vals[j] > 0.f) {
             const int pos = atomicAdd(&ccount, 1);
-            if (pos < 256) clist[pos] = keys[j];
+            if (pos < 256) clist[pos] = key_of(j);
         }
     __syncthreads();
     const int npos = ccount;
@@ -294,10 +298,12 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
         } else if (tid == 0) nfilled = start;
         __syncthreads();
         start = nfilled;
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (!(vals[j] < 0.f)) keys[j] = 0ull;  // only negative peaks are left for the generic rounds
     }
+    if (start >= M) return;  // the usual case: positives and zeros filled the list
+    u64 keys[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)  // generic rounds: everything on list overflow, else only the negative peaks that are left
+        keys[j] = (j < nin && (generic_all || vals[j] < 0.f)) ? key_of(j) : 0ull;
     for (int r = start; r < M; ++r) {
         u64 best = keys[0];
 #pragma unroll
