@@ -7,7 +7,7 @@
 
 #define HH_MAX_EMB 4
 #define HH_MAX_PEOPLE 32  // one wave column per candidate / group in the matching kernel
-#define HH_NMS_TILE 64
+#define HH_NMS_TILE 60  // + the 2-pixel halo of the 5x5 maximum = 64 = one wave of columns
 
 // Where the full-resolution maps come from.
 //  mode 0: computed on the fly -- heat = bilinear x2 of `avg` (the stage-averaged 1/2-res map),

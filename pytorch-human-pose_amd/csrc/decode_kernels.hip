@@ -115,25 +115,83 @@ __device__ __forceinline__ unsigned short bf16_ceil(float f)
 // top_k (grouping.py:147-153).  One workgroup = one 64x64 full-resolution tile of one (b,k)
 // map, computed from L2-resident low-res data; separable 5x5 max through LDS; then M rounds
 // of workgroup-wide arg-max (wave shuffles + one LDS exchange per round).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it parks the wave until every
+// global store it has issued (cell maxima, candidate lists) is acknowledged by memory: a full round trip per barrier that no
+// thread of the workgroup depends on.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifdef HH_NMS_DEBUG  // phase stamps of a sample of workgroups, read by scratch/nms_probe.hip only
+__device__ long long g_nms_dbg[4096 * 8];
+#define NMS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.z == 1 && blockIdx.y < 4) g_nms_dbg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define NMS_STAMP(i)
+#endif
+
 __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src, int M, int tiles_x, u64 *__restrict__ cand_key,
                                                             float *__restrict__ cand_val, float *__restrict__ cellmax)
 {
-    constexpr int TS = HH_NMS_TILE, HS = TS + 4, PR = TS / 2 + 4;
+    // Geometry: a 60x60 tile has a 64x64 halo'ed neighbourhood, so in every pass a wave's 64 lanes are 64 columns (or 64
+    // rows x 4 strips are the 256 threads) with nobody idle.
+    constexpr int TS = HH_NMS_TILE, HS = TS + 4, PR = TS / 2 + 4, SL = TS / 4;  // SL = outputs of one sliding-window strip
+    static_assert(HS == 64 && SL * 4 == TS, "the passes below map 64 lanes to the 64 halo'ed columns");
     __shared__ float v[HS][HS + 1];
     __shared__ float rm[HS][TS + 1];
-    __shared__ float patch[PR][PR + 1];  // half-res source rows/cols of this tile (mode 0)
     __shared__ u64 wbest[2][4];
+    float (*hrow)[HS] = reinterpret_cast<float (*)[HS]>(&rm[0][0]);        // [PR][HS] horizontally interpolated half-res rows
+    float (*patch)[PR + 1] = reinterpret_cast<float (*)[PR + 1]>(&rm[0][0]);  // [PR][PR+1] half-res patch (generic scales)
+    static_assert(sizeof(float) * PR * HS <= sizeof(rm) && sizeof(float) * PR * (PR + 1) <= sizeof(rm), "aliases fit");
     // XCD-aware tile order: workgroups go to the 8 XCDs round-robin by linear block id, so with a multiple of 8 tiles per
     // map, block x lands on XCD x % 8.  Dealing whole tile ROWS to one XCD lets horizontally adjacent tiles share the
-    // 128-byte lines their 2-pixel halos straddle in that XCD's L2 (each tile row of 36 floats touches 3 lines for 144 B).
+    // 128-byte lines their 2-pixel halos straddle in that XCD's L2.
     const int k = blockIdx.y, b = blockIdx.z, ntile = gridDim.x;
     const int tile = (ntile % 8 == 0) ? (blockIdx.x % 8) * (ntile / 8) + blockIdx.x / 8 : blockIdx.x;
     const int ty = tile / tiles_x, tx = tile % tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
     const int tid = threadIdx.x;
+    NMS_STAMP(0);
 
-    if (src.mode == 0) {
-        // stage the half-res neighbourhood once (coalesced), then every full-res value of the tile is the
+    if (src.mode == 0 && src.scale_h2 == 0.5f && src.scale_w2 == 0.5f) {
+        // The stage average is exactly half resolution, so torch's source indices and weights are fixed patterns: even
+        // X = 2c reads half-res (c-1, c) with weights (0.25, 0.75) -- (0, 1) with (1, 0) at X = 0 --, odd X = 2c+1 reads
+        // (c, c+1) with (0.75, 0.25), upper index clamped; rows alike.  Separable, in bilerp()'s order (rows first
+        // interpolated along x, then along y, the same fmaf expressions: bit-identical):
+        //   pass A  lane = full-res column: hrow[r][X] for the 34 half-res rows of the neighbourhood, straight from global;
+        //   pass B  wave = 16 full-res rows (row indices and weights are wave-uniform scalars), lane = column.
+        const int hh = src.H >> 1, wh = src.W >> 1;
+        const float *img = src.avg + ((size_t)b * src.K + k) * hh * wh;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int py0 = src_index(hh, 0.5f, max(y0 - 2, 0)).i0, pry = (y0 - 2) / 2 - py0;  // hrow row of half-res row (y0-2)/2
+        const int X = x0 - 2 + lane, g = X >> 1;  // lane's column; g = floor(X / 2)
+        const bool xb = X <= 0, xodd = X & 1;
+        const int ca = min(xodd ? max(g, 0) : (xb ? max(g, 0) : g - 1), wh - 1), cb = min(ca + 1, wh - 1);
+        const float wxa = xodd ? 0.75f : (xb ? 1.f : 0.25f), wxb = xodd ? 0.25f : (xb ? 0.f : 0.75f);
+        constexpr int NR = (PR + 3) / 4;  // rows per wave; every load is issued before the first use (one round trip, not NR)
+        float ga[NR], gb[NR];
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+            const float *row = img + (size_t)min(py0 + min(wv + 4 * t, PR - 1), hh - 1) * wh;
+            ga[t] = row[ca]; gb[t] = row[cb];
+        }
+#pragma unroll
+        for (int t = 0; t < NR; ++t)
+            if (wv + 4 * t < PR) hrow[wv + 4 * t][lane] = __builtin_fmaf(ga[t], wxa, gb[t] * wxb);
+        lds_barrier();
+        NMS_STAMP(1);
+        const bool xin = X >= 0 && X < src.W;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int Yl = 16 * wv + j, Y = y0 - 2 + Yl, pr = pry + (Yl >> 1);
+            const bool yb = Y <= 0;
+            int ra;
+            float wa, wb;
+            if (j & 1) { ra = max(pr, 0); wa = 0.75f; wb = 0.25f; }
+            else { ra = yb ? max(pr, 0) : pr - 1; wa = yb ? 1.f : 0.25f; wb = yb ? 0.f : 0.75f; }
+            const float val = __builtin_fmaf(hrow[ra][lane], wa, hrow[ra + 1][lane] * wb);
+            v[Yl][lane] = (xin && Y >= 0 && Y < src.H) ? val : -INFINITY;
+        }
+        lds_barrier();  // hrow (aliased on rm) is dead from here
+        NMS_STAMP(2);
+    } else if (src.mode == 0) {
+        // other scales: stage the half-res neighbourhood once (coalesced), then every full-res value of the tile is the
         // same bilinear expression as heat_at(), evaluated from LDS
         const int hh = src.H >> 1, wh = src.W >> 1;
         const int py0 = src_index(hh, src.scale_h2, max(y0 - 2, 0)).i0, px0 = src_index(wh, src.scale_w2, max(x0 - 2, 0)).i0;
@@ -142,37 +200,7 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             const int r = i / PR, c = i % PR;
             patch[r][c] = img[(size_t)min(py0 + r, hh - 1) * wh + min(px0 + c, wh - 1)];
         }
-        __syncthreads();
-        // The stage average is exactly half resolution (scale 0.5), so torch's source indices and weights are fixed
-        // patterns: even X = 2c reads (c-1, c) with weights (0.25, 0.75) -- (c, c+1) with (1, 0) at X = 0 --, odd X reads
-        // (c, c+1) with (0.75, 0.25), the upper index clamped (the patch is filled with clamped rows/columns).  One thread
-        // makes a 2x2 block of full-res values from a 3x3 patch neighbourhood with the same fmaf expressions, in the same
-        // order, as bilerp(): bit-identical, ~8 instead of ~60 instructions per value.
-        if (src.scale_h2 == 0.5f && src.scale_w2 == 0.5f) {
-            const int pry = (y0 - 2) / 2 - py0, prx = (x0 - 2) / 2 - px0;  // patch row/col of half-res index (Y0-2)/2 (may be -1)
-            for (int i = tid; i < (HS / 2) * (HS / 2); i += 256) {
-                const int by = i / (HS / 2), bx = i % (HS / 2);
-                const int Y = y0 - 2 + 2 * by, X = x0 - 2 + 2 * bx;
-                const int pr = pry + by, pc = prx + bx;
-                const bool yin = Y >= 0 && Y < src.H, xin = X >= 0 && X < src.W;
-                const bool yb = Y <= 0, xb = X <= 0;                    // torch clamps the source coordinate at 0
-                const int ra = yb ? max(pr, 0) : pr - 1, rb = ra + 1;  // rows of the even output row
-                const int rc = max(pr, 0), rd = rc + 1;                 // rows of the odd output row
-                const int ca = xb ? max(pc, 0) : pc - 1, cb = ca + 1, cc = max(pc, 0), cd = cc + 1;
-                const float wya = yb ? 1.f : 0.25f, wyb = yb ? 0.f : 0.75f, wxa = xb ? 1.f : 0.25f, wxb = xb ? 0.f : 0.75f;
-                auto hrow = [&](int r, float &e, float &o) {
-                    e = __builtin_fmaf(patch[r][ca], wxa, patch[r][cb] * wxb);
-                    o = __builtin_fmaf(patch[r][cc], 0.75f, patch[r][cd] * 0.25f);
-                };
-                float ae, ao, be, bo, ce, co, de, dodd;
-                hrow(ra, ae, ao); hrow(rb, be, bo); hrow(rc, ce, co); hrow(rd, de, dodd);
-                const bool y1in = Y + 1 >= 0 && Y + 1 < src.H, x1in = X + 1 >= 0 && X + 1 < src.W;
-                v[2 * by][2 * bx] = (yin && xin) ? __builtin_fmaf(ae, wya, be * wyb) : -INFINITY;
-                v[2 * by][2 * bx + 1] = (yin && x1in) ? __builtin_fmaf(ao, wya, bo * wyb) : -INFINITY;
-                v[2 * by + 1][2 * bx] = (y1in && xin) ? __builtin_fmaf(ce, 0.75f, de * 0.25f) : -INFINITY;
-                v[2 * by + 1][2 * bx + 1] = (y1in && x1in) ? __builtin_fmaf(co, 0.75f, dodd * 0.25f) : -INFINITY;
-            }
-        } else
+        lds_barrier();
         for (int i = tid; i < HS * HS; i += 256) {
             const int ly = i / HS, lx = i % HS;
             const int Y = y0 - 2 + ly, X = x0 - 2 + lx;
@@ -186,15 +214,16 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             }
             v[ly][lx] = val;
         }
+        lds_barrier();  // patch (aliased on rm) is dead from here
     } else {
         for (int i = tid; i < HS * HS; i += 256) {
             const int ly = i / HS, lx = i % HS;
             const int Y = y0 - 2 + ly, X = x0 - 2 + lx;
             v[ly][lx] = (Y >= 0 && Y < src.H && X >= 0 && X < src.W) ? heat_at(src, b, k, Y, X) : -INFINITY;
         }
+        lds_barrier();
     }
-    __syncthreads();
-    if (src.mode == 0) {  // exact maximum of every 4x4 full-res cell: the refine kernel prunes with it
+    if (src.mode == 0 && tid < (TS / 4) * (TS / 4)) {  // exact maximum of every 4x4 full-res cell: the refine kernel prunes with it
         const int cy = tid / (TS / 4), cx = tid % (TS / 4);
         const int Y = y0 + 4 * cy, X = x0 + 4 * cx;
         if (Y < src.H && X < src.W) {
@@ -207,43 +236,41 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             reinterpret_cast<unsigned short *>(cellmax)[(((size_t)b * src.K + k) * (src.H >> 2) + (Y >> 2)) * (src.W >> 2) + (X >> 2)] = bf16_ceil(m);
         }
     }
-    // separable 5x5 maximum with sliding windows in registers: 16 outputs from 20 inputs (pair maxima, then pairs of
+    // separable 5x5 maximum with sliding windows in registers: SL outputs from SL+4 inputs (pair maxima, then pairs of
     // pairs, then the fifth element) instead of 5 LDS reads + 4 max per output
-    auto slide16 = [](const float (&in)[20], float (&out)[16]) {
-        float p2[19], p4[17];
+    auto slide = [](const float (&in)[SL + 4], float (&out)[SL]) {
+        float p2[SL + 3], p4[SL + 1];
 #pragma unroll
-        for (int i = 0; i < 19; ++i) p2[i] = fmaxf(in[i], in[i + 1]);
+        for (int i = 0; i < SL + 3; ++i) p2[i] = fmaxf(in[i], in[i + 1]);
 #pragma unroll
-        for (int i = 0; i < 17; ++i) p4[i] = fmaxf(p2[i], p2[i + 2]);
+        for (int i = 0; i < SL + 1; ++i) p4[i] = fmaxf(p2[i], p2[i + 2]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) out[i] = fmaxf(p4[i], in[i + 4]);
+        for (int i = 0; i < SL; ++i) out[i] = fmaxf(p4[i], in[i + 4]);
     };
-    {  // rows 0..63: 64 x 4 strips of 16 outputs, one per thread
-        const int ly = tid / (TS / 16), lx0 = (tid % (TS / 16)) * 16;
-        float in[20], out[16];
+    {  // rows: 64 x 4 strips of SL outputs, one per thread
+        const int ly = tid >> 2, lx0 = (tid & 3) * SL;
+        float in[SL + 4], out[SL];
 #pragma unroll
-        for (int i = 0; i < 20; ++i) in[i] = v[ly][lx0 + i];
-        slide16(in, out);
+        for (int i = 0; i < SL + 4; ++i) in[i] = v[ly][lx0 + i];
+        slide(in, out);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rm[ly][lx0 + i] = out[i];
+        for (int i = 0; i < SL; ++i) rm[ly][lx0 + i] = out[i];
     }
-    {  // rows 64..67: one output per thread (a second strip pass would idle 15 of 16 threads)
-        const int ly = TS + tid / TS, lx = tid % TS;
-        rm[ly][lx] = fmaxf(fmaxf(fmaxf(v[ly][lx], v[ly][lx + 1]), fmaxf(v[ly][lx + 2], v[ly][lx + 3])), v[ly][lx + 4]);
-    }
-    __syncthreads();
-    float vals[16];
-    const int mpx = tid % TS, mpy0 = (tid / TS) * 16;  // this thread's pixels: column mpx, rows mpy0 .. mpy0+15
-    const int nin = (x0 + mpx < src.W) ? min(16, src.H - (y0 + mpy0)) : 0;  // its first `nin` pixels are inside the image
+    lds_barrier();
+    NMS_STAMP(3);
+    float vals[SL];
+    const int mpx = tid & 63, mpy0 = (tid >> 6) * SL;  // this thread's pixels: column mpx (< TS), rows mpy0 .. mpy0+SL-1
+    // its first `nin` pixels are inside the image
+    const int nin = (mpx < TS && x0 + mpx < src.W) ? min(SL, src.H - (y0 + mpy0)) : 0;
     // the sort key of pixel j; only built for the few pixels that need one (positive peaks, the rare generic rounds)
     auto key_of = [&](int j) { return make_key(vals[j], (unsigned)((y0 + mpy0 + j) * src.W + x0 + mpx)); };
-    {
-        float in[20], out[16];
+    if (mpx < TS) {
+        float in[SL + 4], out[SL];
 #pragma unroll
-        for (int i = 0; i < 20; ++i) in[i] = rm[mpy0 + i][mpx];
-        slide16(in, out);
+        for (int i = 0; i < SL + 4; ++i) in[i] = rm[mpy0 + i][mpx];
+        slide(in, out);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < SL; ++j) {
             const float c = v[mpy0 + j + 2][mpx + 2];
             vals[j] = c * ((out[j] == c) ? 1.0f : 0.0f);
         }
@@ -255,19 +282,43 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     __shared__ u64 clist[256];
     __shared__ int ccount, nfilled;
     float (*nv)[TS + 1] = rm;  // reuse: NMS'ed values of the tile
-    __syncthreads();           // everyone is done reading rm
+    lds_barrier();           // everyone is done reading rm
+    NMS_STAMP(4);
     if (tid == 0) { ccount = 0; nfilled = 0; }
+    if (mpx < TS)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) nv[mpy0 + j][mpx] = j < nin ? vals[j] : __builtin_nanf("");  // NaN = outside the image
-    __syncthreads();
+        for (int j = 0; j < SL; ++j) nv[mpy0 + j][mpx] = j < nin ? vals[j] : __builtin_nanf("");  // NaN = outside the image
+    lds_barrier();
+    {  // compact the positive peaks: per-thread counts -> wave prefix sum -> one LDS atomic per wave for the base slot
+        unsigned pm = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (j < nin && vals[j] > 0.f) {
-            const int pos = atomicAdd(&ccount, 1);
-            if (pos < 256) clist[pos] = key_of(j);
+        for (int j = 0; j < SL; ++j) pm |= (j < nin && vals[j] > 0.f) ? (1u << j) : 0u;
+        const int cnt = __popc(pm);
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if ((tid & 63) >= off) incl += o;
         }
-    __syncthreads();
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        int base = 0;
+        if (total) {  // wave-uniform
+            if ((tid & 63) == 0) base = atomicAdd(&ccount, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+        }
+        int pos = base + incl - cnt;
+        const unsigned idx0 = (unsigned)((y0 + mpy0) * src.W + x0 + mpx);
+#pragma unroll
+        for (int j = 0; j < SL; ++j)
+            if (pm & (1u << j)) {  // key of a positive value: make_key() without its special cases
+                if (pos < 256)
+                    clist[pos] = ((u64)(__float_as_uint(vals[j]) | 0x80000000u) << 32) | (u64)(0xffffffffu - (idx0 + (unsigned)(j * src.W)));
+                ++pos;
+            }
+    }
+    lds_barrier();
     const int npos = ccount;
+    NMS_STAMP(5);
     int start = 0;          // first output slot the generic rounds must fill
     bool generic_all = npos > 256;
     if (!generic_all) {
@@ -284,7 +335,7 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
         if (start < M && tid < 64) {  // zero-valued pixels in index order, one tile row per ballot
             int filled = start;
             for (int py = 0; py < TS && filled < M; ++py) {
-                const float z = nv[py][tid];
+                const float z = tid < TS ? nv[py][tid] : 1.f;
                 const bool is0 = (z == 0.f);
                 const u64 mask = __ballot(is0);
                 const int mypos = __popcll(mask & ((1ull << tid) - 1ull));
@@ -296,27 +347,28 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             }
             if (tid == 0) nfilled = filled < M ? filled : M;
         } else if (tid == 0) nfilled = start;
-        __syncthreads();
+        lds_barrier();
         start = nfilled;
     }
+    NMS_STAMP(6);
     if (start >= M) return;  // the usual case: positives and zeros filled the list
-    u64 keys[16];
+    u64 keys[SL];
 #pragma unroll
-    for (int j = 0; j < 16; ++j)  // generic rounds: everything on list overflow, else only the negative peaks that are left
+    for (int j = 0; j < SL; ++j)  // generic rounds: everything on list overflow, else only the negative peaks that are left
         keys[j] = (j < nin && (generic_all || vals[j] < 0.f)) ? key_of(j) : 0ull;
     for (int r = start; r < M; ++r) {
         u64 best = keys[0];
 #pragma unroll
-        for (int j = 1; j < 16; ++j) best = keys[j] > best ? keys[j] : best;
+        for (int j = 1; j < SL; ++j) best = keys[j] > best ? keys[j] : best;
         const u64 wb = wave_max_u64(best);
         if ((tid & 63) == 0) wbest[r & 1][tid >> 6] = wb;
-        __syncthreads();  // one barrier per round: the exchange buffer alternates
+        lds_barrier();  // one barrier per round: the exchange buffer alternates
         u64 g = wbest[r & 1][0];
 #pragma unroll
         for (int w = 1; w < 4; ++w) g = wbest[r & 1][w] > g ? wbest[r & 1][w] : g;
         if (g != 0ull && best == g) {  // keys are unique: exactly one owner
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
+            for (int j = 0; j < SL; ++j)
                 if (keys[j] == g) { cand_val[obase + r] = vals[j]; keys[j] = 0ull; }
         }
         if (tid == 0) cand_key[obase + r] = g;
