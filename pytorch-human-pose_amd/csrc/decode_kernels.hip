@@ -937,7 +937,35 @@ __global__ __launch_bounds__(256) void refine_argmax_kernel(const DecodeSrc src,
             const int ncells = hq * wq;
             float my_ub = -INFINITY;
             int my_cell = -1;
-            for (int c = tid; c < ncells; c += 256) {
+            // Both scans are latency chains if taken one cell at a time (a memory round trip per iteration): U cells' loads are
+            // issued before the first is used.
+            constexpr int U = 8;
+            int c = tid;
+            for (; c + (U - 1) * 256 < ncells; c += U * 256) {
+                unsigned lh[U][HH_MAX_EMB];
+                unsigned short cm[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    cm[u] = cmaxu[c + u * 256];
+#pragma unroll
+                    for (int e = 0; e < HH_MAX_EMB; ++e)
+                        if (e < E) lh[u][e] = tb[(size_t)(c + u * 256) * E + e];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float lb2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < HH_MAX_EMB; ++e)
+                        if (e < E) {
+                            const float lo = __uint_as_float(lh[u][e] << 16), hi = __uint_as_float(lh[u][e] & 0xffff0000u);
+                            const float d = fmaxf(fmaxf(mean[e] - hi, lo - mean[e]), 0.f);
+                            lb2 += d * d;
+                        }
+                    const float ub = __uint_as_float((unsigned)cm[u] << 16) - rintf(__fsqrt_rn(lb2) * (1.f - 2e-6f));  // = cell_ub()
+                    if (ub > my_ub) { my_ub = ub; my_cell = c + u * 256; }
+                }
+            }
+            for (; c < ncells; c += 256) {
                 const float ub = cell_ub(c);
                 if (ub > my_ub) { my_ub = ub; my_cell = c; }
             }
@@ -952,9 +980,25 @@ __global__ __launch_bounds__(256) void refine_argmax_kernel(const DecodeSrc src,
             unsigned gb = (unsigned)(g >> 32);  // invert make_key's order-preserving map
             gb = (gb & 0x80000000u) ? (gb & 0x7fffffffu) : ~gb;
             const float bound = __uint_as_float(gb);
-            for (int c = tid; c < ncells; c += 256) {
-                // ub(c) <= cmax[c] (the distance term is >= 0): most cells are rejected on the cell maximum alone and the
-                // tag bounds (2/3 of the bytes of a scan) are not read again
+            // ub(c) <= cmax[c] (the distance term is >= 0): most cells are rejected on the cell maximum alone and the
+            // tag bounds (2/3 of the bytes of a scan) are not read again
+            constexpr int U2 = 16;
+            c = tid;
+            for (; c + (U2 - 1) * 256 < ncells; c += U2 * 256) {
+                unsigned short cm[U2];
+#pragma unroll
+                for (int u = 0; u < U2; ++u) cm[u] = cmaxu[c + u * 256];
+                unsigned surv = 0;
+#pragma unroll
+                for (int u = 0; u < U2; ++u)
+                    surv |= (c + u * 256 != my_cell && !(__uint_as_float((unsigned)cm[u] << 16) < bound)) ? (1u << u) : 0u;
+                while (surv) {  // rare
+                    const int cc = c + (__builtin_ctz(surv)) * 256;
+                    surv &= surv - 1;
+                    if (cell_ub(cc) >= bound) eval_cell(cc / wq, cc % wq);
+                }
+            }
+            for (; c < ncells; c += 256) {
                 if (c == my_cell || cmax_at(c) < bound) continue;
                 if (cell_ub(c) >= bound) eval_cell(c / wq, c % wq);
             }
