@@ -831,7 +831,7 @@ __global__ __launch_bounds__(256) void tag_bounds_kernel(const DecodeSrc src, fl
 //   min/max of the 3x3 quarter-res tag taps every pixel of the cell interpolates (+ rounding slack).
 // Each thread evaluates its most promising cell exactly, the workgroup maximum of those is a valid lower
 // bound, and only cells with ub >= that bound are evaluated (typically a handful out of H*W/16).
-__global__ __launch_bounds__(256) void refine_argmax_kernel(const DecodeSrc src, int M, const int32_t *__restrict__ ws_jobs,
+__global__ __launch_bounds__(256, 4) void refine_argmax_kernel(const DecodeSrc src, int M, const int32_t *__restrict__ ws_jobs,
                                                             const float *__restrict__ ws_prev, const float *__restrict__ cellmax,
                                                             const float *__restrict__ tagb, u64 *__restrict__ ws_best)
 {
@@ -941,30 +941,22 @@ __global__ __launch_bounds__(256) void refine_argmax_kernel(const DecodeSrc src,
             // issued before the first is used.
             constexpr int U = 8;
             int c = tid;
-            for (; c + (U - 1) * 256 < ncells; c += U * 256) {
-                unsigned lh[U][HH_MAX_EMB];
-                unsigned short cm[U];
+            if (E == 1)  // (the usual single embedding; more dimensions take the plain loop below)
+                for (; c + (U - 1) * 256 < ncells; c += U * 256) {
+                    unsigned lh[U];
+                    unsigned short cm[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    cm[u] = cmaxu[c + u * 256];
+                    for (int u = 0; u < U; ++u) { cm[u] = cmaxu[c + u * 256]; lh[u] = tb[c + u * 256]; }
 #pragma unroll
-                    for (int e = 0; e < HH_MAX_EMB; ++e)
-                        if (e < E) lh[u][e] = tb[(size_t)(c + u * 256) * E + e];
+                    for (int u = 0; u < U; ++u) {
+                        const float lo = __uint_as_float(lh[u] << 16), hi = __uint_as_float(lh[u] & 0xffff0000u);
+                        const float d = fmaxf(fmaxf(mean[0] - hi, lo - mean[0]), 0.f);
+                        float lb2 = 0.f;
+                        lb2 += d * d;
+                        const float ub = __uint_as_float((unsigned)cm[u] << 16) - rintf(__fsqrt_rn(lb2) * (1.f - 2e-6f));  // = cell_ub()
+                        if (ub > my_ub) { my_ub = ub; my_cell = c + u * 256; }
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    float lb2 = 0.f;
-#pragma unroll
-                    for (int e = 0; e < HH_MAX_EMB; ++e)
-                        if (e < E) {
-                            const float lo = __uint_as_float(lh[u][e] << 16), hi = __uint_as_float(lh[u][e] & 0xffff0000u);
-                            const float d = fmaxf(fmaxf(mean[e] - hi, lo - mean[e]), 0.f);
-                            lb2 += d * d;
-                        }
-                    const float ub = __uint_as_float((unsigned)cm[u] << 16) - rintf(__fsqrt_rn(lb2) * (1.f - 2e-6f));  // = cell_ub()
-                    if (ub > my_ub) { my_ub = ub; my_cell = c + u * 256; }
-                }
-            }
             for (; c < ncells; c += 256) {
                 const float ub = cell_ub(c);
                 if (ub > my_ub) { my_ub = ub; my_cell = c; }
