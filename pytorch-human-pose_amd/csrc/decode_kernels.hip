@@ -802,24 +802,34 @@ __global__ __launch_bounds__(64) void refine_mean_kernel(const DecodeSrc src, in
 // (1b) per (b,k) quarter-res cell: [lo, hi] of the 3x3 tag taps (slack included) -- shared by every person
 __global__ __launch_bounds__(256) void tag_bounds_kernel(const DecodeSrc src, float *__restrict__ tagb)
 {
+    // thread = one quarter-res column x TBR consecutive rows: the 3-wide row minima / maxima are made once per source row and
+    // slide down the column (3.75 loads per cell instead of 9; clamped border rows / columns repeat a tap, which min / max ignore)
+    constexpr int TBR = 8;
     const int hq = src.H >> 2, wq = src.W >> 2, E = src.E;
     const int k = blockIdx.y, b = blockIdx.z;
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < hq * wq; c += gridDim.x * 256) {
-        const int qy = c / wq, qx = c % wq;
-        const int ya = max(qy - 1, 0), yb = min(qy + 1, hq - 1), xa = max(qx - 1, 0), xb = min(qx + 1, wq - 1);
+    const int nrb = (hq + TBR - 1) / TBR;
+    for (int it = blockIdx.x * 256 + threadIdx.x; it < nrb * wq; it += gridDim.x * 256) {
+        const int qx = it % wq, qy0 = (it / wq) * TBR;
+        const int xa = max(qx - 1, 0), xb = min(qx + 1, wq - 1);
         for (int e = 0; e < E; ++e) {
             const float *tq = src.tags_q[e] + (size_t)b * src.tags_bs[e] + (size_t)k * hq * wq;
-            float lo = INFINITY, hi = -INFINITY;
-            for (int y = ya; y <= yb; ++y)
-                for (int x = xa; x <= xb; ++x) {
-                    const float t = tq[(size_t)y * wq + x];
-                    lo = fminf(lo, t); hi = fmaxf(hi, t);
-                }
-            const float slack = 1e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-30f;  // >> 3 roundings of a convex combination
-            // stored as a bf16 pair in one dword (lo rounded DOWN, hi rounded UP: the bound only gets looser), which halves
-            // what the arg-max scans have to read per cell
-            reinterpret_cast<unsigned *>(tagb)[(((size_t)b * src.K + k) * hq * wq + c) * E + e] =
-                (unsigned)bf16_floor(lo - slack) | ((unsigned)bf16_ceil(hi + slack) << 16);
+            float rlo[TBR + 2], rhi[TBR + 2];
+#pragma unroll
+            for (int r = 0; r < TBR + 2; ++r) {
+                const float *row = tq + (size_t)min(max(qy0 - 1 + r, 0), hq - 1) * wq;
+                const float t0 = row[xa], t1 = row[qx], t2 = row[xb];
+                rlo[r] = fminf(fminf(t0, t1), t2); rhi[r] = fmaxf(fmaxf(t0, t1), t2);
+            }
+#pragma unroll
+            for (int r = 0; r < TBR; ++r) {
+                if (qy0 + r >= hq) break;
+                const float lo = fminf(fminf(rlo[r], rlo[r + 1]), rlo[r + 2]), hi = fmaxf(fmaxf(rhi[r], rhi[r + 1]), rhi[r + 2]);
+                const float slack = 1e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-30f;  // >> 3 roundings of a convex combination
+                // stored as a bf16 pair in one dword (lo rounded DOWN, hi rounded UP: the bound only gets looser), which
+                // halves what the arg-max scans have to read per cell
+                reinterpret_cast<unsigned *>(tagb)[(((size_t)b * src.K + k) * hq * wq + (size_t)(qy0 + r) * wq + qx) * E + e] =
+                    (unsigned)bf16_floor(lo - slack) | ((unsigned)bf16_ceil(hi + slack) << 16);
+            }
         }
     }
 }
@@ -1031,7 +1041,7 @@ hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32
                          unsigned long long *ws_best, int32_t *ws_jobs, const float *cellmax, float *tagb, hipStream_t s)
 {
     if (src.mode == 0)
-        hipLaunchKernelGGL(tag_bounds_kernel, dim3(((src.H >> 2) * (src.W >> 2) + 255) / 256, src.K, src.B), dim3(256), 0, s, src, tagb);
+        hipLaunchKernelGGL(tag_bounds_kernel, dim3(((((src.H >> 2) + 7) / 8) * (src.W >> 2) + 255) / 256, src.K, src.B), dim3(256), 0, s, src, tagb);  // 8 = TBR
     hipError_t e = hipMemsetAsync(ws_best, 0, (size_t)src.B * M * src.K * sizeof(u64), s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws_jobs, 0, 32, s);  // the 8 queue counters
