@@ -121,12 +121,12 @@ __device__ __forceinline__ unsigned short bf16_ceil(float f)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef HH_NMS_DEBUG  // phase stamps of a sample of workgroups, read by scratch/nms_probe.hip only
 __device__ long long g_nms_dbg[4096 * 8];
-#define NMS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.z == 1 && blockIdx.y < 4) g_nms_dbg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define NMS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x >= 8192 && blockIdx.x < 8192 + 4096) g_nms_dbg[(blockIdx.x - 8192) * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define NMS_STAMP(i)
 #endif
 
-__global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src, int M, int tiles_x, u64 *__restrict__ cand_key,
+__global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src, int M, int tiles_x, int ntile, u64 *__restrict__ cand_key,
                                                             float *__restrict__ cand_val, float *__restrict__ cellmax)
 {
     // Geometry: a 60x60 tile has a 64x64 halo'ed neighbourhood, so in every pass a wave's 64 lanes are 64 columns (or 64
@@ -139,11 +139,12 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     float (*hrow)[HS] = reinterpret_cast<float (*)[HS]>(&rm[0][0]);        // [PR][HS] horizontally interpolated half-res rows
     float (*patch)[PR + 1] = reinterpret_cast<float (*)[PR + 1]>(&rm[0][0]);  // [PR][PR+1] half-res patch (generic scales)
     static_assert(sizeof(float) * PR * HS <= sizeof(rm) && sizeof(float) * PR * (PR + 1) <= sizeof(rm), "aliases fit");
-    // XCD-aware tile order: workgroups go to the 8 XCDs round-robin by linear block id, so with a multiple of 8 tiles per
-    // map, block x lands on XCD x % 8.  Dealing whole tile ROWS to one XCD lets horizontally adjacent tiles share the
-    // 128-byte lines their 2-pixel halos straddle in that XCD's L2.
-    const int k = blockIdx.y, b = blockIdx.z, ntile = gridDim.x;
-    const int tile = (ntile % 8 == 0) ? (blockIdx.x % 8) * (ntile / 8) + blockIdx.x / 8 : blockIdx.x;
+    // XCD-aware work order: workgroups go to the 8 XCDs round-robin by linear block id.  Each XCD takes a contiguous eighth of
+    // the (image, joint, tile) list, i.e. whole maps: all tiles of a map, with the 128-byte lines their 2-pixel halos share,
+    // go through one L2.
+    const int total = gridDim.x;
+    const int unit = (total % 8 == 0) ? (blockIdx.x % 8) * (total / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int tile = unit % ntile, k = (unit / ntile) % src.K, b = unit / (ntile * src.K);
     const int ty = tile / tiles_x, tx = tile % tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
     const int tid = threadIdx.x;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             vals[j] = c * ((out[j] == c) ? 1.0f : 0.0f);
         }
     }
-    const size_t obase = ((((size_t)b * src.K + k) * gridDim.x) + tile) * M;
+    const size_t obase = ((((size_t)b * src.K + k) * ntile) + tile) * M;
     // The tile's ordering is: positive peaks (value desc), then zero-valued pixels (index asc), then negative
     // peaks.  Fast path: positives are compacted and ranked in LDS, zeros are taken row by row with ballots;
     // the generic M-round arg-max below only runs for what is left (negative peaks) or on list overflow.
@@ -378,8 +379,8 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
 hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, u64 *cand_key, float *cand_val, float *cellmax, hipStream_t s)
 {
     const int tiles_x = (src.W + HH_NMS_TILE - 1) / HH_NMS_TILE, tiles_y = (src.H + HH_NMS_TILE - 1) / HH_NMS_TILE;
-    hipLaunchKernelGGL(nms_tile_topk_kernel, dim3(tiles_x * tiles_y, src.K, src.B), dim3(256), 0, s, src, M, tiles_x, cand_key,
-                       cand_val, cellmax);
+    hipLaunchKernelGGL(nms_tile_topk_kernel, dim3(tiles_x * tiles_y * src.K * src.B), dim3(256), 0, s, src, M, tiles_x,
+                       tiles_x * tiles_y, cand_key, cand_val, cellmax);
     return hipGetLastError();
 }
 
