@@ -170,27 +170,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 
     static_for<NL>([&](auto jc) { load_unit(jc, 0); });
 
-    // ---- accumulators start at the bias.  The residual is read now, 16 bytes per lane (couts 16m+8h..+7 of the lane's
-    //      pixel), but not touched before the epilogue: it is a third of the bytes a residual conv reads, and consumed here
-    //      it sat on the critical path of the first chunk (every workgroup of a launch starts with the same HBM burst).
+    // ---- accumulators start at bias (+ residual).  The residual is read 16 bytes per lane (couts 16m+8h..+7 of the
+    //      lane's pixel) and the two half-waves exchange halves with v_permlane32_swap into the MFMA C layout.
     f32x16 acc[NT][PT];
-    u32x4 rv[PT][NT][2];
-    if (p.res) {
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const int oy = oy0 + (wp * PT + pt) * RPT + dy, ox = ox0 + dx;
-            const bool valid = oy < p.Ho && ox < p.Wo;
-            const size_t pix = valid ? ((size_t)b * p.Hob + (oy * p.osy + ooy)) * p.Wob + (ox * p.osx + oox) : 0;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 16 * m + 8 * h;
-                    const bool ok = valid && c0 < p.cout_store;
-                    rv[pt][nt][m] = *reinterpret_cast<const u32x4 *>(p.res + pix * p.res_cs + p.res_coff + (ok ? c0 : 0));
-                }
-        }
-    }
     {
         float4 bs[NT][4];
 #pragma unroll
@@ -198,15 +180,41 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 bs[nt][g] = *reinterpret_cast<const float4 *>(p.bias + cg * COUT_T + (wc * NT + nt) * 32 + 8 * g + 4 * h);
+        u32x4 rv[PT][NT][2];
+        if (p.res) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int oy = oy0 + (wp * PT + pt) * RPT + dy, ox = ox0 + dx;
+                const bool valid = oy < p.Ho && ox < p.Wo;
+                const size_t pix = valid ? ((size_t)b * p.Hob + (oy * p.osy + ooy)) * p.Wob + (ox * p.osx + oox) : 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int c0 = cg * COUT_T + (wc * NT + nt) * 32 + 16 * m + 8 * h;
+                        const bool ok = valid && c0 < p.cout_store;
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(p.res + pix * p.res_cs + p.res_coff + (ok ? c0 : 0));
+                        rv[pt][nt][m] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+                    }
+            }
+        }
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
+                    unsigned x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+                    if (p.res) {
+                        auto s0 = __builtin_amdgcn_permlane32_swap(rv[pt][nt][m][0], rv[pt][nt][m][2], false, false);
+                        auto s1 = __builtin_amdgcn_permlane32_swap(rv[pt][nt][m][1], rv[pt][nt][m][3], false, false);
+                        x0 = s0[0]; y0 = s0[1]; x1 = s1[0]; y1 = s1[1];
+                    }
                     const float4 ba = bs[nt][2 * m], bb = bs[nt][2 * m + 1];
-                    acc[nt][pt][8 * m + 0] = ba.x; acc[nt][pt][8 * m + 1] = ba.y; acc[nt][pt][8 * m + 2] = ba.z; acc[nt][pt][8 * m + 3] = ba.w;
-                    acc[nt][pt][8 * m + 4] = bb.x; acc[nt][pt][8 * m + 5] = bb.y; acc[nt][pt][8 * m + 6] = bb.z; acc[nt][pt][8 * m + 7] = bb.w;
+                    acc[nt][pt][8 * m + 0] = ba.x + bf16_lo(x0); acc[nt][pt][8 * m + 1] = ba.y + bf16_hi(x0);
+                    acc[nt][pt][8 * m + 2] = ba.z + bf16_lo(x1); acc[nt][pt][8 * m + 3] = ba.w + bf16_hi(x1);
+                    acc[nt][pt][8 * m + 4] = bb.x + bf16_lo(y0); acc[nt][pt][8 * m + 5] = bb.y + bf16_hi(y0);
+                    acc[nt][pt][8 * m + 6] = bb.z + bf16_lo(y1); acc[nt][pt][8 * m + 7] = bb.w + bf16_hi(y1);
                 }
     }
 
@@ -314,26 +322,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     mfma_chunk(std::false_type{}, nchunks - 1);
     CONV_STAMP(5);
 
-    // ---- epilogue: (+ residual: the two half-waves exchange halves of its 16 bytes with v_permlane32_swap into the MFMA C
-    //      layout; a pixel / channel group outside the output contributes nothing that is stored) (ReLU) -> fp32 NCHW
-    //      directly, or bf16 NHWC with the half-waves paired by v_permlane32_swap so that every lane stores 16 contiguous
-    //      bytes (couts 16m+8h..+7 of its pixel) straight from registers.
-    if (p.res) {
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    auto s0 = __builtin_amdgcn_permlane32_swap(rv[pt][nt][m][0], rv[pt][nt][m][2], false, false);
-                    auto s1 = __builtin_amdgcn_permlane32_swap(rv[pt][nt][m][1], rv[pt][nt][m][3], false, false);
-                    const unsigned x0 = s0[0], y0 = s0[1], x1 = s1[0], y1 = s1[1];
-                    acc[nt][pt][8 * m + 0] += bf16_lo(x0); acc[nt][pt][8 * m + 1] += bf16_hi(x0);
-                    acc[nt][pt][8 * m + 2] += bf16_lo(x1); acc[nt][pt][8 * m + 3] += bf16_hi(x1);
-                    acc[nt][pt][8 * m + 4] += bf16_lo(y0); acc[nt][pt][8 * m + 5] += bf16_hi(y0);
-                    acc[nt][pt][8 * m + 6] += bf16_lo(y1); acc[nt][pt][8 * m + 7] += bf16_hi(y1);
-                }
-    }
+    // ---- epilogue: (ReLU) -> fp32 NCHW directly, or bf16 NHWC with the half-waves paired by v_permlane32_swap so
+    //      that every lane stores 16 contiguous bytes (couts 16m+8h..+7 of its pixel) straight from registers.
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int oy = oy0 + (wp * PT + pt) * RPT + dy, ox = ox0 + dx;
