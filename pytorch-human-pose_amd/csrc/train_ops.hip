@@ -63,16 +63,28 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const bf16_raw *__restr
     // thread = (pixel lane pl = tid / C8, channel group g = tid % C8) over 8 channels; C % 8 == 0, C <= 2048
     const int C8 = C / 8, g = threadIdx.x % C8, pl = threadIdx.x / C8, npl = 256 / C8;
     double s[8] = {}, q[8] = {};
-    if (pl < npl)
-        for (size_t p = (size_t)blockIdx.x * npl + pl; p < P; p += (size_t)gridDim.x * npl) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(x + p * cs + g * 8);
+    if (pl < npl) {
+        // UB pixels per trip, their loads issued together: one load in flight per thread is a memory round trip per 16 bytes
+        constexpr int UB = 4;
+        const size_t step = (size_t)gridDim.x * npl;
+        auto add = [&](const uint4 &v) {
             const unsigned u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float a = __builtin_bit_cast(float, u[i] << 16), b = __builtin_bit_cast(float, u[i] & 0xffff0000u);
                 s[2 * i] += a; q[2 * i] += (double)a * a; s[2 * i + 1] += b; q[2 * i + 1] += (double)b * b;
             }
+        };
+        size_t p = (size_t)blockIdx.x * npl + pl;
+        for (; p + (UB - 1) * step < P; p += UB * step) {
+            uint4 v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) v[u] = *reinterpret_cast<const uint4 *>(x + (p + u * step) * cs + g * 8);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) add(v[u]);
         }
+        for (; p < P; p += step) add(*reinterpret_cast<const uint4 *>(x + p * cs + g * 8));
+    }
     __shared__ double sh[2][256][8 + 1];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sh[0][threadIdx.x][i] = s[i]; sh[1][threadIdx.x][i] = q[i]; }
@@ -159,25 +171,42 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const bf16_raw *__r
 {
     const int C8 = C / 8, g = threadIdx.x % C8, pl = threadIdx.x / C8, npl = 256 / C8;
     double s[8] = {}, q[8] = {};
-    if (pl < npl)
-        for (size_t p = (size_t)blockIdx.x * npl + pl; p < P; p += (size_t)gridDim.x * npl) {
-            const uint4 xv = *reinterpret_cast<const uint4 *>(x + p * cs + g * 8);
-            const uint4 yv = *reinterpret_cast<const uint4 *>(y + p * cs + g * 8);
-            const uint4 dv = *reinterpret_cast<const uint4 *>(dy + p * cs + g * 8);
+    if (pl < npl) {
+        float mu[8], is[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { mu[i] = mean[g * 8 + i]; is[i] = invstd[g * 8 + i]; }
+        auto add = [&](const uint4 &xv, const uint4 &yv, const uint4 &dv) {
             const unsigned xu[4] = {xv.x, xv.y, xv.z, xv.w}, yu[4] = {yv.x, yv.y, yv.z, yv.w}, du[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int c = g * 8 + 2 * k + h;
                     const float xf = __builtin_bit_cast(float, h ? (xu[k] & 0xffff0000u) : (xu[k] << 16));
                     const float yf = __builtin_bit_cast(float, h ? (yu[k] & 0xffff0000u) : (yu[k] << 16));
                     float gf = __builtin_bit_cast(float, h ? (du[k] & 0xffff0000u) : (du[k] << 16));
                     if (relu && !(yf > 0.f)) gf = 0.f;
                     s[2 * k + h] += gf;
-                    q[2 * k + h] += (double)gf * ((xf - mean[c]) * invstd[c]);
+                    q[2 * k + h] += (double)gf * ((xf - mu[2 * k + h]) * is[2 * k + h]);
                 }
+        };
+        constexpr int UB = 2;  // 3 tensors x UB pixels in flight per thread
+        const size_t step = (size_t)gridDim.x * npl;
+        size_t p = (size_t)blockIdx.x * npl + pl;
+        for (; p + (UB - 1) * step < P; p += UB * step) {
+            uint4 xv[UB], yv[UB], dv[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                xv[u] = *reinterpret_cast<const uint4 *>(x + (p + u * step) * cs + g * 8);
+                yv[u] = *reinterpret_cast<const uint4 *>(y + (p + u * step) * cs + g * 8);
+                dv[u] = *reinterpret_cast<const uint4 *>(dy + (p + u * step) * cs + g * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) add(xv[u], yv[u], dv[u]);
         }
+        for (; p < P; p += step)
+            add(*reinterpret_cast<const uint4 *>(x + p * cs + g * 8), *reinterpret_cast<const uint4 *>(y + p * cs + g * 8),
+                *reinterpret_cast<const uint4 *>(dy + p * cs + g * 8));
+    }
     __shared__ double sh[2][256][8 + 1];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sh[0][threadIdx.x][i] = s[i]; sh[1][threadIdx.x][i] = q[i]; }
