@@ -106,9 +106,9 @@ def train_bench(args, pkg, dist, rank, world, dev):
     net.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()})
     net = net.to(dev).train()
     model = net
-    if dist is not None:  # base/model.py:36-48 with the reference trainer's default sync_batchnorm=True (trainer.py:44)
+    if dist is not None:  # base/model.py:36-48; experiments/keypoints/higher_hrnet_32.yaml:17 sets sync_batchnorm: false
         wrapper = pkg.keypoints.KeypointsModel(net)
-        wrapper.to_DDP(dev.index, use_batchnorm=True)
+        wrapper.to_DDP(dev.index, use_batchnorm=False)
         model = wrapper.net
     loss_fn = pkg.AEKeypointsLoss()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
@@ -151,7 +151,7 @@ def train_bench(args, pkg, dist, rank, world, dev):
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"HigherHRNet-W32 training step, batch {B} @ 512x512 per GPU: forward (train-mode BN) + AE loss + "
                                    f"backward + Adam, {args.people} people/image", "global_batch": world * B,
-                       "parallelism": f"DistributedDataParallel x{world} (gradient all-reduce + SyncBatchNorm statistics on RCCL)" if world > 1 else "single GPU",
+                       "parallelism": f"DistributedDataParallel x{world} (gradient all-reduce on RCCL, BatchNorm per rank as in the reference's experiment file)" if world > 1 else "single GPU",
                        "final_loss": round(float(loss.item()), 5),
                        "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)},
         }), flush=True)

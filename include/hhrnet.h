@@ -195,8 +195,8 @@ int hh_bn_train_forward(const void *x, int64_t P, int C, const float *gamma, con
 int hh_bn_train_backward(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd,
                          const float *gamma, int relu, void *dx, void *dres, float *dgamma, float *dbeta, double *scratch, void *stream);
 
-/* SyncBatchNorm (src/base/model.py:42-44: `to_DDP(..., use_batchnorm=True)` converts every BatchNorm2d, the default of
- * the reference's DDP training, trainer.py:44,253): the two passes above split around their one exchange step.
+/* SyncBatchNorm (src/base/model.py:42-44: `to_DDP(..., use_batchnorm=True)` converts every BatchNorm2d, the reference
+ * trainer's default, trainer.py:44,253; experiments/keypoints/higher_hrnet_32.yaml:17 turns it off): the two passes above split around their one exchange step.
  *   hh_bn_train_stats:          sums[2c], sums[2c+1] = sum x, sum x^2 over THIS rank's P pixels (doubles).
  *   -- the caller all-reduces (SUM) sums and the pixel count over the ranks (RCCL) --
  *   hh_bn_train_normalize:      mean / invstd from the global sums and count, then the same apply pass.

@@ -69,7 +69,8 @@ class KeypointsModel:
         self.net = self.net.cuda(device_id)
 
     def to_DDP(self, device_id: int, use_batchnorm: bool) -> None:
-        """base/model.py:36-48.  `use_batchnorm` is the reference's SyncBatchNorm switch (its trainer's default): here the
+        """base/model.py:36-48.  `use_batchnorm` is the reference's SyncBatchNorm switch (its trainer's default; the HigherHRNet
+        experiment file sets `sync_batchnorm: false`): here the
         BatchNorm leaves stay what they are and the training forward shares their statistics across the ranks of the default
         process group (hh_bn_train_stats -> all-reduce -> hh_bn_train_normalize).  Gradients: torch DDP's bucketed
         all-reduce on RCCL, overlapped with the backward."""
