@@ -568,6 +568,13 @@ def test_train_step_under_distributed_data_parallel(pkg):
         torch.cuda.synchronize()
         for (n, a), (_, b) in zip(plain.named_parameters(), ddp.module.named_parameters()):
             assert b.grad is not None and torch.equal(a.grad, b.grad), n
+        # KeypointsModel.to_DDP with bf16 gradient buckets: the same gradients to bf16 precision
+        model = importlib.import_module(PKG + ".keypoints.model").KeypointsModel(make())
+        model.to_DDP(0, use_batchnorm=False, bf16_gradients=True)
+        grads(model.net)
+        torch.cuda.synchronize()
+        for (n, a), (_, b) in zip(plain.named_parameters(), model.net.module.named_parameters()):
+            assert b.grad is not None and (a.grad - b.grad).abs().max() <= 8e-3 * a.grad.abs().max() + 1e-12, n
     finally:
         if created:
             dist.destroy_process_group()
