@@ -390,45 +390,68 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const DecodeSrc src, in
                                                          const float *__restrict__ cand_val, float *__restrict__ tags_k,
                                                          int32_t *__restrict__ coords_k, float *__restrict__ scores_k)
 {
-    __shared__ u64 wbest[4];
-    __shared__ int wpos[4];
+    constexpr int NST = 4096;  // candidate keys of a map staged in LDS when they fit (81 tiles x 30 at 512x512)
+    __shared__ u64 skeys[NST];
+    __shared__ u64 wbest[2][4];
+    __shared__ int wpos[2][4];
+    __shared__ u64 win_key[HH_MAX_PEOPLE];
+    __shared__ int win_pos[HH_MAX_PEOPLE];
     const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int N = ntiles * M;
-    u64 *keys = cand_key + ((size_t)b * src.K + k) * N;
+    u64 *gkeys = cand_key + ((size_t)b * src.K + k) * N;
     const float *vals = cand_val + ((size_t)b * src.K + k) * N;
     const size_t obase = ((size_t)b * src.K + k) * M;
-    for (int r = 0; r < M; ++r) {
+    const bool staged = N <= NST;  // else the rounds scan (and consume) the global list
+    if (staged) {
+        for (int i = tid; i < N; i += 256) skeys[i] = gkeys[i];
+        __syncthreads();
+    }
+    for (int r = 0; r < M; ++r) {  // M rounds of workgroup-wide arg-max; one barrier per round (the exchange buffer alternates)
         u64 best = 0ull;
         int pos = -1;
-        for (int i = tid; i < N; i += 256) {
-            const u64 kk = keys[i];
-            if (kk > best) { best = kk; pos = i; }
+        if (staged) {
+            for (int i = tid; i < N; i += 256) {
+                const u64 kk = skeys[i];
+                if (kk > best) { best = kk; pos = i; }
+            }
+        } else {
+            for (int i = tid; i < N; i += 256) {
+                const u64 kk = gkeys[i];
+                if (kk > best) { best = kk; pos = i; }
+            }
         }
         const u64 wb = wave_max_u64(best);
-        if (best == wb && best != 0ull) { wbest[tid >> 6] = wb; wpos[tid >> 6] = pos; }
-        else if ((tid & 63) == 0 && wb == 0ull) { wbest[tid >> 6] = 0ull; wpos[tid >> 6] = -1; }
+        if (best == wb && best != 0ull) { wbest[r & 1][tid >> 6] = wb; wpos[r & 1][tid >> 6] = pos; }  // keys are unique: one owner
+        else if ((tid & 63) == 0 && wb == 0ull) { wbest[r & 1][tid >> 6] = 0ull; wpos[r & 1][tid >> 6] = -1; }
         __syncthreads();
         u64 g = 0ull;
         int gp = -1;
 #pragma unroll
         for (int w = 0; w < 4; ++w)
-            if (wbest[w] > g) { g = wbest[w]; gp = wpos[w]; }
-        if (tid == 0) {
-            float sc = 0.f;
-            int x = 0, y = 0;
-            if (gp >= 0) {
-                const unsigned idx = 0xffffffffu - (unsigned)(g & 0xffffffffull);
-                sc = vals[gp];
-                x = (int)(idx % (unsigned)src.W);
-                y = (int)(idx / (unsigned)src.W);
-                keys[gp] = 0ull;
-            }
-            scores_k[obase + r] = sc;
-            coords_k[(obase + r) * 2 + 0] = x;
-            coords_k[(obase + r) * 2 + 1] = y;
-            for (int e = 0; e < src.E; ++e) tags_k[(obase + r) * src.E + e] = tag_at(src, b, k, y, x, e);
+            if (wbest[r & 1][w] > g) { g = wbest[r & 1][w]; gp = wpos[r & 1][w]; }
+        if (gp >= 0 && pos == gp) {  // the owner retires its candidate before anyone scans again
+            if (staged) skeys[gp] = 0ull; else gkeys[gp] = 0ull;
         }
-        __syncthreads();
+        if (tid == 0) { win_key[r] = g; win_pos[r] = gp; }
+        if (!staged) __syncthreads();  // global list: the retirement must be visible to the next scan
+    }
+    __syncthreads();
+    // outputs of the M winners in parallel: score, x = idx % w, y = idx / w, tags gathered at (y, x) (grouping.py:152-170)
+    if (tid < M) {
+        const u64 g = win_key[tid];
+        const int gp = win_pos[tid];
+        float sc = 0.f;
+        int x = 0, y = 0;
+        if (gp >= 0) {
+            const unsigned idx = 0xffffffffu - (unsigned)(g & 0xffffffffull);
+            sc = vals[gp];
+            x = (int)(idx % (unsigned)src.W);
+            y = (int)(idx / (unsigned)src.W);
+        }
+        scores_k[obase + tid] = sc;
+        coords_k[(obase + tid) * 2 + 0] = x;
+        coords_k[(obase + tid) * 2 + 1] = y;
+        for (int e = 0; e < src.E; ++e) tags_k[(obase + tid) * src.E + e] = tag_at(src, b, k, y, x, e);
     }
 }
 
