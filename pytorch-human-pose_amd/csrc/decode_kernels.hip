@@ -700,13 +700,53 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
             if (lane < na) S.assign[lane] = star;
             __syncthreads();
         }
-        if (lane == 0) {  // dict semantics of grouping.py:104-143, candidates in row order
+        // dict semantics of grouping.py:104-143.  A candidate matched to a group appends to that group only (the assignment is
+        // one-to-one), so the matched ones are applied by their own lanes; what must stay in candidate order on lane 0 are the
+        // unmatched ones (new keys, max_num_people cut-off).  The one interaction - an unmatched candidate whose key equals the
+        // key of an EXISTING group resets that group's list, before or after a matched append depending on the order - sends
+        // the whole joint down the serial path.
+        bool matched = false;
+        int mcol = -1;
+        if (!first && lane < na) {
+            mcol = S.assign[lane];
+            matched = mcol >= 0 && mcol < ng && S.saved[lane * MLD + mcol] < tag_thr;
+        }
+        const u64 allmask = (1ull << na) - 1ull;  // na <= M <= 32
+        const u64 mmask = __ballot(matched);
+        u64 serial = allmask;
+        if (mmask) {
+            const u64 umask = allmask & ~mmask;
+            bool collide = false;
+            if (umask) {
+                const float gk = lane < S.G ? S.gkey[lane] : __builtin_nanf("");
+                const int myk = lane < na ? __float_as_int(S.ctag[lane * HH_MAX_EMB]) : 0;
+                for (u64 um = umask; um; um &= um - 1) {
+                    const float key = __int_as_float(__builtin_amdgcn_readlane(myk, __builtin_ctzll(um)));
+                    collide |= __ballot(gk == key) != 0ull;
+                }
+            }
+            if (!collide) {
+                if (matched) {
+                    const int t = mcol, pos = S.gnt[t];
+                    float *jr = J + ((size_t)t * K + idx) * D;
+                    jr[0] = (float)S.cj[lane * 3 + 0]; jr[1] = (float)S.cj[lane * 3 + 1]; jr[2] = (float)S.cj[lane * 3 + 2];
+                    for (int e = 0; e < E; ++e) {
+                        jr[3 + e] = S.ctag[lane * HH_MAX_EMB + e];
+                        GT[((size_t)t * (K + 1) + pos) * E + e] = S.ctag[lane * HH_MAX_EMB + e];
+                    }
+                    S.gnt[t] = pos + 1;
+                }
+                serial = umask;
+                __syncthreads();
+            }
+        }
+        if (lane == 0) {  // candidates in row order
             int Gc = S.G;
-            for (int a = 0; a < na; ++a) {
+            for (u64 sm = serial; sm; sm &= sm - 1) {
+                const int a = __builtin_ctzll(sm);
                 int t;
-                bool append = false;
                 const int col = first ? -1 : S.assign[a];
-                if (!first && col >= 0 && col < ng && S.saved[a * MLD + col] < tag_thr) { t = col; append = true; }
+                if (!first && col >= 0 && col < ng && S.saved[a * MLD + col] < tag_thr) t = col;
                 else {
                     const float key = S.ctag[a * HH_MAX_EMB];
                     t = -1;
@@ -725,7 +765,6 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
                     GT[((size_t)t * (K + 1) + S.gnt[t]) * E + e] = S.ctag[a * HH_MAX_EMB + e];
                 }
                 S.gnt[t] += 1;
-                (void)append;
             }
             S.G = Gc;
         }
