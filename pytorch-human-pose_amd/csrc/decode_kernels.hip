@@ -136,6 +136,8 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     __shared__ float v[HS][HS + 1];
     __shared__ float rm[HS][TS + 1];
     __shared__ u64 wbest[2][4];
+    __shared__ u64 clist[256];
+    __shared__ int ccount, nfilled, need_rows;
     float (*hrow)[HS] = reinterpret_cast<float (*)[HS]>(&rm[0][0]);        // [PR][HS] horizontally interpolated half-res rows
     float (*patch)[PR + 1] = reinterpret_cast<float (*)[PR + 1]>(&rm[0][0]);  // [PR][PR+1] half-res patch (generic scales)
     static_assert(sizeof(float) * PR * HS <= sizeof(rm) && sizeof(float) * PR * (PR + 1) <= sizeof(rm), "aliases fit");
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     const int y0 = ty * TS, x0 = tx * TS;
     const int tid = threadIdx.x;
     NMS_STAMP(0);
+    if (tid == 0) { ccount = 0; nfilled = 0; need_rows = 0; }  // (several barriers before their first use)
 
     if (src.mode == 0 && src.scale_h2 == 0.5f && src.scale_w2 == 0.5f) {
         // The stage average is exactly half resolution, so torch's source indices and weights are fixed patterns: even
@@ -280,16 +283,8 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     // The tile's ordering is: positive peaks (value desc), then zero-valued pixels (index asc), then negative
     // peaks.  Fast path: positives are compacted and ranked in LDS, zeros are taken row by row with ballots;
     // the generic M-round arg-max below only runs for what is left (negative peaks) or on list overflow.
-    __shared__ u64 clist[256];
-    __shared__ int ccount, nfilled;
-    float (*nv)[TS + 1] = rm;  // reuse: NMS'ed values of the tile
-    lds_barrier();           // everyone is done reading rm
+    float (*nv)[TS + 1] = rm;  // reuse (rare path below): NMS'ed values of the tile
     NMS_STAMP(4);
-    if (tid == 0) { ccount = 0; nfilled = 0; }
-    if (mpx < TS)
-#pragma unroll
-        for (int j = 0; j < SL; ++j) nv[mpy0 + j][mpx] = j < nin ? vals[j] : __builtin_nanf("");  // NaN = outside the image
-    lds_barrier();
     {  // compact the positive peaks: per-thread counts -> wave prefix sum -> one LDS atomic per wave for the base slot
         unsigned pm = 0;
 #pragma unroll
@@ -333,22 +328,47 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             }
         }
         start = npos < M ? npos : M;
-        if (start < M && tid < 64) {  // zero-valued pixels in index order, one tile row per ballot
+        // zero-valued pixels in index order, one tile row per ballot.  The first SL rows are wave 0's own pixels (registers);
+        // they almost always hold the M - npos zeros still wanted.
+        if (start < M && tid < 64) {
             int filled = start;
-            for (int py = 0; py < TS && filled < M; ++py) {
-                const float z = tid < TS ? nv[py][tid] : 1.f;
-                const bool is0 = (z == 0.f);
-                const u64 mask = __ballot(is0);
-                const int mypos = __popcll(mask & ((1ull << tid) - 1ull));
-                if (is0 && filled + mypos < M) {
-                    cand_key[obase + filled + mypos] = make_key(z, (unsigned)((y0 + py) * src.W + x0 + tid));
-                    cand_val[obase + filled + mypos] = z;
+#pragma unroll
+            for (int j = 0; j < SL; ++j)
+                if (filled < M) {  // wave-uniform
+                    const bool is0 = j < nin && vals[j] == 0.f;
+                    const u64 mask = __ballot(is0);
+                    const int mypos = __popcll(mask & ((1ull << tid) - 1ull));
+                    if (is0 && filled + mypos < M) {
+                        cand_key[obase + filled + mypos] = make_key(vals[j], (unsigned)((y0 + j) * src.W + x0 + tid));
+                        cand_val[obase + filled + mypos] = vals[j];
+                    }
+                    filled += __popcll(mask);
                 }
-                filled += __popcll(mask);
-            }
-            if (tid == 0) nfilled = filled < M ? filled : M;
+            if (tid == 0) { nfilled = filled < M ? filled : M; need_rows = filled < M; }
         } else if (tid == 0) nfilled = start;
         lds_barrier();
+        if (need_rows) {  // rare (a tile with fewer than M pixels in its first rows): the other waves' rows through LDS
+            if (mpx < TS)
+#pragma unroll
+                for (int j = 0; j < SL; ++j) nv[mpy0 + j][mpx] = j < nin ? vals[j] : __builtin_nanf("");  // NaN = outside the image
+            lds_barrier();
+            if (tid < 64) {
+                int filled = nfilled;
+                for (int py = SL; py < TS && filled < M; ++py) {
+                    const float z = tid < TS ? nv[py][tid] : 1.f;
+                    const bool is0 = (z == 0.f);
+                    const u64 mask = __ballot(is0);
+                    const int mypos = __popcll(mask & ((1ull << tid) - 1ull));
+                    if (is0 && filled + mypos < M) {
+                        cand_key[obase + filled + mypos] = make_key(z, (unsigned)((y0 + py) * src.W + x0 + tid));
+                        cand_val[obase + filled + mypos] = z;
+                    }
+                    filled += __popcll(mask);
+                }
+                if (tid == 0) nfilled = filled < M ? filled : M;
+            }
+            lds_barrier();
+        }
         start = nfilled;
     }
     NMS_STAMP(6);
