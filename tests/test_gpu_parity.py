@@ -648,18 +648,18 @@ def test_training_loop_reduces_the_loss(pkg):
     K, S, B = 17, 128, 4
     net = pkg.HigherHRNet(K, 32)
     net.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()})
-    net = net.to(DEV).train()
-    loss_fn, opt = pkg.AEKeypointsLoss(), torch.optim.Adam(net.parameters(), lr=1e-3)
-    x = torch.from_numpy(pkg.synth.synth_images(B, S, S, 0)).to(DEV)
+    # through the reference's own wrappers: KeypointsModel (model.py:15-40) + KeypointsModule.training_step (module.py:43-71)
+    km = importlib.import_module(PKG + ".keypoints.model")
+    model = km.KeypointsModel(net)
+    model.to_CUDA(0)
+    model.net.train()
+    module = km.KeypointsModule(model, pkg.AEKeypointsLoss(), torch.optim.Adam(model.net.parameters(), lr=1e-3))
+    x = torch.from_numpy(pkg.synth.synth_images(B, S, S, 0))
     hms, masks, joints = pkg.synth.synth_train_targets(B, K, S, 3, seed=0)
-    hms, masks = [torch.from_numpy(h).to(DEV) for h in hms], [torch.from_numpy(m).to(DEV) for m in masks]
-    losses = []
-    for _ in range(15):
-        ph, pt = net(x)
-        hl, push, pull = loss_fn.calculate_loss(ph, pt, hms, masks, joints)
-        loss = hl[0] + hl[1] + push[0] + pull[0]
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
-        losses.append(loss.item())
+    batch = module.batch_to_device((x, [torch.from_numpy(h) for h in hms], [torch.from_numpy(m) for m in masks], joints))
+    assert batch[0].device.type == "cuda" and batch[1][0].device.type == "cuda"
+    metrics = [module.training_step(batch, i) for i in range(15)]
+    losses = [m["loss"] for m in metrics]
+    assert set(metrics[0]) == {"loss", "hm_0_loss", "hm_1_loss", "push_0_loss", "pull_0_loss"}
+    assert abs(metrics[0]["loss"] - sum(v for k, v in metrics[0].items() if k != "loss")) < 1e-4 * abs(metrics[0]["loss"]) + 1e-6
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] / 5, losses
