@@ -115,18 +115,34 @@ class _AEGroupingFn(torch.autograd.Function):
         return (ctx.gpush * g_push + ctx.gpull * g_pull).to(ctx.dtype), None, None
 
 
+class DeviceJoints:
+    """The joints of a batch already packed and uploaded (`upload_joints`): lets a caller keep the host -> device copy out
+    of the step, e.g. to capture the whole training step in a hipGraph.  Not in the reference (it passes host lists)."""
+
+    def __init__(self, packed: Tensor, counts: Tensor):
+        self.packed, self.counts = packed, counts
+
+    def __len__(self) -> int:
+        return int(self.counts.shape[0])
+
+
+def upload_joints(joints: list, K: int, h: int, w: int, device) -> DeviceJoints:
+    packed, counts = pack_joints(joints, K, h, w)
+    return DeviceJoints(torch.from_numpy(packed).to(device), torch.from_numpy(counts).to(device))
+
+
 class AEGroupingLoss(_Loss):
     """loss.py:19-61 -> (push_loss / batch, pull_loss / batch)"""
 
-    def forward(self, pred_tags: Tensor, joints: list) -> tuple[Tensor, Tensor]:
+    def forward(self, pred_tags: Tensor, joints) -> tuple[Tensor, Tensor]:
         if not pred_tags.is_cuda:
             raise _lib.HHError("pred_tags must be a CUDA/HIP tensor: there is no CPU path")
         B, K, h, w = pred_tags.shape
         if len(joints) != B:
             raise ValueError(f"joints has {len(joints)} entries for a batch of {B}")
-        packed, counts = pack_joints(joints, K, h, w)
-        dev = pred_tags.device
-        return _AEGroupingFn.apply(pred_tags, torch.from_numpy(packed).to(dev), torch.from_numpy(counts).to(dev))
+        if not isinstance(joints, DeviceJoints):
+            joints = upload_joints(joints, K, h, w, pred_tags.device)
+        return _AEGroupingFn.apply(pred_tags, joints.packed, joints.counts)
 
 
 class AEKeypointsLoss(_Loss):

@@ -148,9 +148,10 @@ def deconv_k4s2(x: Tensor, m: nn.ConvTranspose2d) -> Tensor:
     y = torch.empty((B, cout, 2 * H, 2 * W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)  # every phase is written
     for py in range(2):
         for px in range(2):
-            ky = [3, 1] if py == 0 else [2, 0]
-            kx = [3, 1] if px == 0 else [2, 0]
-            w = wt[:, :, ky][:, :, :, kx].permute(1, 0, 2, 3)  # [cout, cin, 2, 2]
+            ky = (3, 1) if py == 0 else (2, 0)
+            kx = (3, 1) if px == 0 else (2, 0)
+            # (slices + stack, not list indexing: no index tensor is uploaded, so the step can be captured in a hipGraph)
+            w = torch.stack([torch.stack([wt[:, :, a, b] for b in kx], -1) for a in ky], -2).permute(1, 0, 2, 3)  # [cout, cin, 2, 2]
             w = F.pad(w, (0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout))
             yp = _ConvFn.apply(x, w.contiguous(), 1, (1 - py, 1 - px))[:, :cout]
             y[:, :, py::2, px::2] = yp

@@ -390,6 +390,12 @@ def test_ae_loss_and_gradients_match_reference(pkg):
     pu, pl = lossmod.AEGroupingLoss()(t, [np.array([[[1, 1, 1]] * 17, [[2, 2, 1]] * 17], np.int32)])
     (pu * 1024.0).backward()
     assert abs(pu.item() - 0.5) < 1e-7 and pl.item() == 0 and float(t.grad.abs().max()) == 0.0  # equal tags: exp(0), zero slope
+    # joints uploaded ahead of the step (DeviceJoints, e.g. for a captured step) give the same losses as the host list
+    tt = torch.randn(2, 17, 8, 8, device=DEV)
+    jl = [np.array([[[1, 1, 1]] * 17, [[5, 2, 1]] * 17], np.int32), np.array([[[3, 6, 1]] * 17], np.int32)]
+    a = lossmod.AEGroupingLoss()(tt, jl)
+    b = lossmod.AEGroupingLoss()(tt, lossmod.upload_joints(jl, 17, 8, 8, DEV))
+    assert a[0].item() == b[0].item() and a[1].item() == b[1].item()
     with pytest.raises(IndexError):
         lossmod.AEGroupingLoss()(t, [np.array([[[8, 1, 1]] * 17], np.int32)])
     with pytest.raises(pkg._lib.HHError):
