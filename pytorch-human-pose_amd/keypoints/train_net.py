@@ -119,7 +119,11 @@ def flush_running_stats() -> None:
     mods = [t[0] for t in _PENDING_STATS]
     moms = {(m.momentum if m.momentum is not None else 0.1) for m in mods}
     means = [t[1] for t in _PENDING_STATS]
-    var_unb = [(1.0 / (t[2] * t[2]) - t[0].eps) * (t[3] / max(t[3] - 1, 1)) for t in _PENDING_STATS]
+    # unbiased batch variance = (1 / invstd^2 - eps) * n / (n - 1), for all layers in four multi-tensor launches
+    invstds = [t[2] for t in _PENDING_STATS]
+    var_unb = torch._foreach_reciprocal(torch._foreach_mul(invstds, invstds))
+    torch._foreach_sub_(var_unb, [float(t[0].eps) for t in _PENDING_STATS])
+    torch._foreach_mul_(var_unb, [float(t[3]) / max(float(t[3]) - 1.0, 1.0) for t in _PENDING_STATS])
     if len(moms) == 1:
         mom = moms.pop()
         rm, rv = [m.running_mean for m in mods], [m.running_var for m in mods]
