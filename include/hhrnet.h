@@ -190,6 +190,17 @@ int hh_conv2d_wgrad(const void *x, const void *dy, int B, int H, int W, int cin,
                     void *workspace, void *stream);
 int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int cout, int ks, int stride, int mode, int pad_y, int pad_x,
               const float *bias, const void *res, int relu, void *y, void *workspace, void *stream);
+/* The same convolution with weights packed ahead of it.  A training step packs ~700 weight sets (forward layout and
+ * data-gradient layout of every conv); as separate launches that is ~700 tiny dependent kernels whose launch gaps cost more
+ * than the packing.  hh_pack_conv_weights_batch packs n weight sets in ONE launch: w[i] fp32 [cout][cin][ks][ks] (device
+ * pointers in a HOST array), packed[i] device buffers of hh_conv2d_packed_elems(cin, cout, ks, stride, mode) bf16 elements,
+ * shapes host int32 [n][5] = cout, cin, ks, stride, mode (modes as in hh_conv2d), descs_dev a device scratch of
+ * n * 4 * 64 bytes.  hh_conv2d_packed = hh_conv2d on such a buffer (bias NULL or a multiple of 32 long).  The packed copy
+ * is valid until the fp32 weights change (the optimizer step).                                                            */
+int64_t hh_conv2d_packed_elems(int cin, int cout, int ks, int stride, int mode);
+int hh_pack_conv_weights_batch(int n, const float *const *w, void *const *packed, const int32_t *shapes, void *descs_dev, void *stream);
+int hh_conv2d_packed(const void *x, int B, int H, int W, int cin, const void *w_packed, int cout, int ks, int stride, int mode, int pad_y,
+                     int pad_x, const float *bias, const void *res, int relu, void *y, void *stream);
 int hh_bn_train_forward(const void *x, int64_t P, int C, const float *gamma, const float *beta, float eps, const void *res, int relu,
                         void *y, float *mean, float *invstd, double *scratch, void *stream);
 int hh_bn_train_backward(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd,

@@ -77,6 +77,9 @@ def _sig(lib):
         "hh_conv2d_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
         "hh_bn_train_forward": (i32, [vp, i64, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, vp, vp]),
         "hh_bn_train_backward": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+        "hh_conv2d_packed_elems": (i64, [i32, i32, i32, i32, i32]),
+        "hh_pack_conv_weights_batch": (i32, [i32, vp, vp, vp, vp, vp]),
+        "hh_conv2d_packed": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
         "hh_bn_train_stats": (i32, [vp, i64, i32, vp, vp, vp]),
         "hh_bn_train_normalize": (i32, [vp, i64, i32, vp, dbl, vp, vp, C.c_float, vp, i32, vp, vp, vp, vp]),
         "hh_bn_train_backward_stats": (i32, [vp, vp, vp, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp]),

@@ -1,5 +1,6 @@
 // extern "C" surface declared in include/hhrnet.h (network part).
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/hhrnet.h"
@@ -174,28 +175,45 @@ int64_t hh_conv2d_workspace_bytes(int cin, int cout, int ks, int mode)
     return (int64_t)coutp * cin_pad * ks * ks * 2 + (int64_t)coutp * 4 + 512;
 }
 
-int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int cout, int ks, int stride, int mode, int pad_y, int pad_x,
-              const float *bias, const void *res, int relu, void *y, void *workspace, void *stream)
+// Shape bookkeeping shared by hh_conv2d / hh_conv2d_packed / hh_pack_conv_weights_batch: the conv that actually runs for
+// (cin, cout, ks, stride, mode) and the size of one packed weight set.
+struct Conv2dPlan {
+    int ci, co, coutp, kks, kstride, KC, NT, COUT_T, cin_pad, nsets;
+    size_t wel;  // bf16 elements of ONE packed set (mode 2 has four: the output-parity phases)
+};
+static int conv2d_plan(int cin, int cout, int ks, int stride, int mode, Conv2dPlan *pl, const char *who)
+{
+    pl->ci = mode ? cout : cin; pl->co = mode ? cin : cout;  // channels of the conv that actually runs
+    if (pl->ci % 16 || pl->co % 8) { hh_set_error((std::string(who) + ": input channels must be a multiple of 16 and output channels of 8").c_str()); return 1; }
+    if (mode == 1 && stride != 1) { hh_set_error((std::string(who) + ": mode 1 is the data gradient of a stride-1 convolution").c_str()); return 1; }
+    if (ks == 2 && stride != 1) { hh_set_error((std::string(who) + ": 2x2 kernels run at stride 1 only").c_str()); return 1; }
+    if (mode == 2 && (stride != 2 || ks != 3)) { hh_set_error((std::string(who) + ": mode 2 is the data gradient of a 3x3 stride-2 convolution").c_str()); return 1; }
+    pl->coutp = round_up_i(pl->co, 32);
+    pl->kks = mode == 2 ? 2 : ks; pl->kstride = mode == 2 ? 1 : stride;  // kernel that actually runs
+    if (hh_family_pick(pl->kks, pl->kstride, pl->ci, pl->coutp, &pl->KC, &pl->NT)) { hh_set_error((std::string(who) + ": no kernel family for this shape").c_str()); return 1; }
+    pl->COUT_T = 32 * pl->NT; pl->cin_pad = round_up_i(pl->ci, pl->KC);
+    pl->wel = (size_t)pl->coutp * pl->cin_pad * pl->kks * pl->kks;
+    pl->nsets = mode == 2 ? 4 : 1;
+    return 0;
+}
+
+// w: fp32 weights (packed into `workspace` here) or, with prepacked != NULL, weight sets packed by hh_pack_conv_weights_batch
+static int conv2d_impl(const void *x, int B, int H, int W, int cin, const float *w, const bf16_raw *prepacked, int cout, int ks, int stride,
+                       int mode, int pad_y, int pad_x, const float *bias, const void *res, int relu, void *y, void *workspace, void *stream,
+                       const char *who)
 {
     if (pad_y < 0) pad_y = (ks - 1) / 2;
     if (pad_x < 0) pad_x = (ks - 1) / 2;
     static bool inited = false;
     if (!inited) { HH_CHECK_HIP(conv_init()); inited = true; }
-    const int ci = mode ? cout : cin, co = mode ? cin : cout;  // channels of the conv that actually runs
-    if (!x || !w || !y || !workspace || B <= 0 || H <= 0 || W <= 0) { hh_set_error("hh_conv2d: bad argument"); return 1; }
-    if (ci % 16 || co % 8) { hh_set_error("hh_conv2d: input channels must be a multiple of 16 and output channels of 8"); return 1; }
-    if (mode == 1 && stride != 1) { hh_set_error("hh_conv2d: mode 1 is the data gradient of a stride-1 convolution"); return 1; }
-    if (ks == 2 && stride != 1) { hh_set_error("hh_conv2d: 2x2 kernels run at stride 1 only"); return 1; }
+    if (!x || (!w && !prepacked) || !y || (!workspace && !prepacked) || B <= 0 || H <= 0 || W <= 0) { hh_set_error((std::string(who) + ": bad argument").c_str()); return 1; }
+    Conv2dPlan pl;
+    if (conv2d_plan(cin, cout, ks, stride, mode, &pl, who)) return 1;
     if (mode == 1) { pad_y = ks - 1 - pad_y; pad_x = ks - 1 - pad_x; }  // the adjoint correlates with the rotated kernel
-    if (mode == 2 && (stride != 2 || ks != 3)) { hh_set_error("hh_conv2d: mode 2 is the data gradient of a 3x3 stride-2 convolution"); return 1; }
-    const int coutp = round_up_i(co, 32);
-    const int kks = mode == 2 ? 2 : ks, kstride = mode == 2 ? 1 : stride;  // kernel that actually runs
-    int KC = 0, NT = 0;
-    if (hh_family_pick(kks, kstride, ci, coutp, &KC, &NT)) { hh_set_error("hh_conv2d: no kernel family for this shape"); return 1; }
-    const int COUT_T = 32 * NT, cin_pad = round_up_i(ci, KC);
-    const size_t wel = (size_t)coutp * cin_pad * kks * kks;
+    const int co = pl.co, coutp = pl.coutp, KC = pl.KC, COUT_T = pl.COUT_T;
+    const size_t wel = pl.wel;
     bf16_raw *packed = (bf16_raw *)workspace;
-    float *zbias = (float *)((char *)workspace + ((wel * 2 + 255) & ~(size_t)255));
+    float *zbias = workspace ? (float *)((char *)workspace + ((wel * 2 + 255) & ~(size_t)255)) : nullptr;
     hipStream_t s = (hipStream_t)stream;
     // the kernel reads coutp bias values: an all-zero device array serves the bias-free case (no memset per call), a bias
     // whose length is already a multiple of 32 is used in place, anything else is copied behind the packed weights
@@ -203,37 +221,90 @@ int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int c
     if (!bias && coutp <= 4096) {
         if (!zeros) { HH_CHECK_HIP(hipMalloc((void **)&zeros, 4096 * 4)); HH_CHECK_HIP(hipMemset(zeros, 0, 4096 * 4)); }
         zbias = zeros;
+    } else if (bias && co == coutp) {
+        zbias = const_cast<float *>(bias);
+    } else if (!workspace) {
+        hh_set_error((std::string(who) + ": without a workspace the bias must be NULL or have a multiple of 32 entries").c_str());
+        return 1;
     } else if (!bias) {
         HH_CHECK_HIP(hipMemsetAsync(zbias, 0, (size_t)coutp * 4, s));
-    } else if (co == coutp) {
-        zbias = const_cast<float *>(bias);
     } else {
         HH_CHECK_HIP(hipMemcpyAsync(zbias, bias, (size_t)co * 4, hipMemcpyDeviceToDevice, s));
     }
-    const int Ho = kstride == 2 ? H / 2 : H, Wo = kstride == 2 ? W / 2 : W;
-    const int cfg = hh_pick_config(kks, kstride, KC, NT, Wo);
-    if (cfg < 0) { hh_set_error("hh_conv2d: no kernel instantiation for this shape"); return 1; }
+    const int Ho = pl.kstride == 2 ? H / 2 : H, Wo = pl.kstride == 2 ? W / 2 : W;
+    const int cfg = hh_pick_config(pl.kks, pl.kstride, KC, pl.NT, Wo);
+    if (cfg < 0) { hh_set_error((std::string(who) + ": no kernel instantiation for this shape").c_str()); return 1; }
     const ConvConfig &cc = conv_config(cfg);
     ConvParams p{};
-    p.in = (const bf16_raw *)x; p.in_cs = ci; p.Hin = H; p.Win = W;
-    p.w = packed; p.bias = zbias;
+    p.in = (const bf16_raw *)x; p.in_cs = pl.ci; p.Hin = H; p.Win = W;
+    p.w = prepacked ? prepacked : packed; p.bias = zbias;
     p.res = (const bf16_raw *)res; p.res_cs = co;
     p.out = (bf16_raw *)y; p.out_cs = co;
     p.Ho = Ho; p.Wo = Wo; p.Hob = Ho; p.Wob = Wo; p.osy = p.osx = 1;
-    p.cin = cin_pad; p.cout_real = co; p.cout_store = co; p.relu = relu;
+    p.cin = pl.cin_pad; p.cout_real = co; p.cout_store = co; p.relu = relu;
     p.pad_y = pad_y; p.pad_x = pad_x; p.B = B;
     p.tiles_x = (Wo + cc.TW - 1) / cc.TW; p.tiles_y = (Ho + cc.th() - 1) / cc.th(); p.ncg = coutp / cc.cout_t();
     if (mode == 2) {  // four output-parity phases, each a 2x2 conv over dL/dy scattered onto the 2H x 2W grid
         p.Hob = 2 * H; p.Wob = 2 * W; p.osy = p.osx = 2; p.pad_y = p.pad_x = 0;
         for (int ph = 0; ph < 4; ++ph) {
-            HH_CHECK_HIP(launch_pack_weights(w, cout, cin, 2, 2, KC, COUT_T, packed, wel, s, ph >> 1, ph & 1));
+            if (prepacked) p.w = prepacked + (size_t)ph * wel;
+            else HH_CHECK_HIP(launch_pack_weights(w, cout, cin, 2, 2, KC, COUT_T, packed, wel, s, ph >> 1, ph & 1));
             p.ooy = ph >> 1; p.oox = ph & 1;
             HH_CHECK_HIP(conv_launch(cfg, p, s));
         }
         return 0;
     }
-    HH_CHECK_HIP(launch_pack_weights(w, cout, cin, ks, mode, KC, COUT_T, packed, wel, s));
+    if (!prepacked) HH_CHECK_HIP(launch_pack_weights(w, cout, cin, ks, mode, KC, COUT_T, packed, wel, s));
     HH_CHECK_HIP(conv_launch(cfg, p, s));
+    return 0;
+}
+
+int hh_conv2d(const void *x, int B, int H, int W, int cin, const float *w, int cout, int ks, int stride, int mode, int pad_y, int pad_x,
+              const float *bias, const void *res, int relu, void *y, void *workspace, void *stream)
+{
+    if (!w || !workspace) { hh_set_error("hh_conv2d: bad argument"); return 1; }
+    return conv2d_impl(x, B, H, W, cin, w, nullptr, cout, ks, stride, mode, pad_y, pad_x, bias, res, relu, y, workspace, stream, "hh_conv2d");
+}
+
+int hh_conv2d_packed(const void *x, int B, int H, int W, int cin, const void *w_packed, int cout, int ks, int stride, int mode, int pad_y,
+                     int pad_x, const float *bias, const void *res, int relu, void *y, void *stream)
+{
+    if (!w_packed) { hh_set_error("hh_conv2d_packed: bad argument"); return 1; }
+    return conv2d_impl(x, B, H, W, cin, nullptr, (const bf16_raw *)w_packed, cout, ks, stride, mode, pad_y, pad_x, bias, res, relu, y, nullptr,
+                       stream, "hh_conv2d_packed");
+}
+
+int64_t hh_conv2d_packed_elems(int cin, int cout, int ks, int stride, int mode)
+{
+    Conv2dPlan pl;
+    if (conv2d_plan(cin, cout, ks, stride, mode, &pl, "hh_conv2d_packed_elems")) return -1;
+    return (int64_t)(pl.wel * pl.nsets);
+}
+
+int hh_pack_conv_weights_batch(int n, const float *const *w, void *const *packed, const int32_t *shapes, void *descs_dev, void *stream)
+{
+    if (n < 0 || (n && (!w || !packed || !shapes || !descs_dev))) { hh_set_error("hh_pack_conv_weights_batch: bad argument"); return 1; }
+    std::vector<PackDesc> d;
+    d.reserve((size_t)n * 4);
+    for (int i = 0; i < n; ++i) {
+        const int cout = shapes[5 * i], cin = shapes[5 * i + 1], ks = shapes[5 * i + 2], stride = shapes[5 * i + 3], mode = shapes[5 * i + 4];
+        Conv2dPlan pl;
+        if (!w[i] || !packed[i] || conv2d_plan(cin, cout, ks, stride, mode, &pl, "hh_pack_conv_weights_batch")) {
+            if (w[i] && packed[i]) return 1;
+            hh_set_error("hh_pack_conv_weights_batch: null pointer in the table");
+            return 1;
+        }
+        for (int ph = 0; ph < pl.nsets; ++ph) {
+            PackDesc e{};
+            e.W = w[i]; e.packed = (bf16_raw *)packed[i] + (size_t)ph * pl.wel; e.total = (long long)pl.wel;
+            e.cout = cout; e.cin = cin; e.ks = pl.kks; e.mode = mode; e.KC = pl.KC; e.COUT_T = pl.COUT_T; e.py = ph >> 1; e.px = ph & 1;
+            d.push_back(e);
+        }
+    }
+    if (d.empty()) return 0;
+    // (pageable source: the copy is staged before hipMemcpyAsync returns, so the vector may go)
+    HH_CHECK_HIP(hipMemcpyAsync(descs_dev, d.data(), d.size() * sizeof(PackDesc), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HH_CHECK_HIP(launch_pack_weights_batch((const PackDesc *)descs_dev, (int)d.size(), (hipStream_t)stream));
     return 0;
 }
 

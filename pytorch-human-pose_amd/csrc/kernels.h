@@ -133,6 +133,14 @@ hipError_t launch_ae_grouping(const float *tags, int64_t tags_bs, const int32_t 
 
 // Training building blocks (train_ops.hip)
 #define HH_BN_BLOCKS 256  // partial-sum blocks of the BatchNorm reductions; scratch = HH_BN_BLOCKS * C * 2 doubles
+// one weight set of a batched packing launch (launch_pack_weights_batch)
+struct PackDesc {
+    const float *W;
+    bf16_raw *packed;
+    long long total;
+    int cout, cin, ks, mode, KC, COUT_T, py, px;
+};
+hipError_t launch_pack_weights_batch(const PackDesc *descs_dev, int n, hipStream_t s);
 hipError_t launch_pack_weights(const float *W, int cout, int cin, int ks, int mode, int KC, int COUT_T, bf16_raw *packed, size_t total,
                                hipStream_t s, int py = 0, int px = 0);
 hipError_t launch_bn_train_forward(const bf16_raw *x, int cs, size_t P, int C, const float *gamma, const float *beta, float eps,

@@ -17,12 +17,12 @@ __device__ __forceinline__ bf16_raw f2bf_dev(float f) { return __builtin_bit_cas
 //   mode 2: data gradient of a 3x3 stride-2 conv, one output-parity phase (py, px) as a 2x2 conv over dL/dy:
 //           dX[2i+py, 2j+px] = sum_t W'[t] dY[i + ty, j + tx];  even parity uses the centre tap only (ty = 0 <-> ky = 1),
 //           odd parity ty = 0 <-> ky = 2 and ty = 1 <-> ky = 0 (same in x).  `ks` is then 2 (the packed kernel size).
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ W, int cout, int cin, int ks, int mode, int KC,
-                                                           int COUT_T, bf16_raw *__restrict__ packed, size_t total, int py, int px)
+__device__ __forceinline__ void pack_weights_range(const float *__restrict__ W, int cout, int cin, int ks, int mode, int KC, int COUT_T,
+                                                   bf16_raw *__restrict__ packed, size_t total, int py, int px, size_t first, size_t step)
 {
     const int co_eff = mode ? cin : cout, ci_eff = mode ? cout : cin;
     const int cin_pad = (ci_eff + KC - 1) / KC * KC, nch = cin_pad / KC, taps = ks * ks, C8 = KC / 8;
-    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+    for (size_t o = first; o < total; o += step) {
         size_t r = o;
         const int j = r % 8; r /= 8;
         const int co_in = r % COUT_T; r /= COUT_T;
@@ -44,6 +44,26 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
         }
         packed[o] = f2bf_dev(v);
     }
+}
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ W, int cout, int cin, int ks, int mode, int KC,
+                                                           int COUT_T, bf16_raw *__restrict__ packed, size_t total, int py, int px)
+{
+    pack_weights_range(W, cout, cin, ks, mode, KC, COUT_T, packed, total, py, px, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+// Every weight set of a training step in ONE launch (blockIdx.y = descriptor): ~700 tiny dependent launches per step cost more
+// in launch gaps than the packing itself.
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackDesc *__restrict__ descs)
+{
+    const PackDesc d = descs[blockIdx.y];
+    pack_weights_range(d.W, d.cout, d.cin, d.ks, d.mode, d.KC, d.COUT_T, d.packed, (size_t)d.total, d.py, d.px,
+                       (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+
+hipError_t launch_pack_weights_batch(const PackDesc *descs_dev, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(32, n), dim3(256), 0, s, descs_dev);
+    return hipGetLastError();
 }
 
 hipError_t launch_pack_weights(const float *W, int cout, int cin, int ks, int mode, int KC, int COUT_T, bf16_raw *packed, size_t total,

@@ -19,18 +19,18 @@ from . import train_ops as ops
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: Tensor, w: Tensor, stride: int, pad):
+    def forward(ctx, x: Tensor, w: Tensor, stride: int, pad, packed_fwd=None, packed_bwd=None):
         ctx.save_for_backward(x, w)
-        ctx.stride, ctx.pad = stride, pad
-        return ops.conv2d(x, w, stride, pad=pad)
+        ctx.stride, ctx.pad, ctx.packed_bwd = stride, pad, packed_bwd
+        return ops.conv2d(x, w, stride, pad=pad, packed=packed_fwd)
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         x, w = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dx = ops.conv2d(dy, w, ctx.stride, data_grad=True, pad=ctx.pad) if ctx.needs_input_grad[0] else None
+        dx = ops.conv2d(dy, w, ctx.stride, data_grad=True, pad=ctx.pad, packed=ctx.packed_bwd) if ctx.needs_input_grad[0] else None
         dw = ops.conv2d_weight_grad(x, dy, w.shape[-1], ctx.stride, pad=ctx.pad) if ctx.needs_input_grad[1] else None
-        return dx, dw, None, None
+        return dx, dw, None, None, None, None
 
 
 class _BNFn(torch.autograd.Function):
@@ -74,12 +74,38 @@ def conv(x: Tensor, m: nn.Conv2d, stride: int | None = None) -> Tensor:
         w = F.pad(w, (0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout))
     if x.shape[1] != cin_p:
         x = F.pad(x, (0, 0, 0, 0, 0, cin_p - x.shape[1]))
-    y = _ConvFn.apply(x.contiguous(memory_format=torch.channels_last), w, stride, None)
+    pk = _PACKED[0].get((id(m.weight), stride)) if (_PACKED[0] is not None and w is m.weight) else None
+    y = _ConvFn.apply(x.contiguous(memory_format=torch.channels_last), w, stride, None, *(pk if pk is not None else (None, None)))
     if cout_p != cout:
         y = y[:, :cout]
     if m.bias is not None:
         y = y + m.bias.view(1, -1, 1, 1).to(y.dtype)
     return y
+
+
+_PACKED: list = [None]  # {(id(weight), stride): (forward-packed, data-gradient-packed)} of the forward in flight (_refresh_packed)
+
+
+def _refresh_packed(net) -> None:
+    """Pack the weights of every conv whose channel counts the kernels take unpadded - forward layout and data-gradient
+    layout - in ONE launch per step (ops.PackedConvWeights) instead of one launch per conv call.  The copies are read by this
+    forward and the backward that follows it; they go stale with the optimizer step and are refreshed by the next forward."""
+    cache = getattr(net, "_train_packed", None)
+    if cache is None or not cache[0].pointers_current():
+        entries, index = [], {}
+        for m in net.modules():
+            if isinstance(m, nn.Conv2d) and m.weight.is_cuda and m.weight.dtype == torch.float32:
+                cout, cin, ks, _ = m.weight.shape
+                stride = m.stride[0]
+                if cin % 16 or cout % 16 or (id(m.weight), stride) in index:
+                    continue
+                index[(id(m.weight), stride)] = (len(entries), len(entries) + 1)
+                entries += [(m.weight, stride, False), (m.weight, stride, True)]
+        pw = ops.PackedConvWeights(entries)
+        cache = (pw, {k: (pw.buffers[a], pw.buffers[b]) for k, (a, b) in index.items()})
+        net._train_packed = cache
+    cache[0].refresh()
+    _PACKED[0] = cache[1]
 
 
 _SYNC: list = [None]  # process group of the forward in flight when the net was converted to SyncBatchNorm (else None)
@@ -209,6 +235,7 @@ def higher_hrnet_train_forward(net, images: Tensor):
     bb = net.backbone
     _PENDING_STATS.clear()
     _SYNC[0] = getattr(net, "sync_batchnorm", None)  # set by KeypointsModel.to_DDP(..., use_batchnorm=True)
+    _refresh_packed(net)
     x = images.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     x = bn(conv(x, bb.conv1), bb.bn1, relu=True)
     x = bn(conv(x, bb.conv2), bb.bn2, relu=True)

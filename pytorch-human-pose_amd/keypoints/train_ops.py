@@ -16,13 +16,30 @@ def _nhwc(x: Tensor) -> Tensor:
 
 
 def conv2d(x: Tensor, w: Tensor, stride: int = 1, bias: Tensor | None = None, res: Tensor | None = None, relu: bool = False,
-           data_grad: bool = False, pad: tuple[int, int] | None = None) -> Tensor:
+           data_grad: bool = False, pad: tuple[int, int] | None = None, packed: Tensor | None = None) -> Tensor:
     """y = act(conv(x, w) + bias (+ res)), padding (ks-1)/2.  data_grad=True: x is dL/dy of the conv with weights
-    w [cout,cin,ks,ks] and this stride, and the result is dL/dx (stride 2: 3x3 only, even input sizes)."""
+    w [cout,cin,ks,ks] and this stride, and the result is dL/dx (stride 2: 3x3 only, even input sizes).
+    packed: the weights of this (w, stride, data_grad) already packed by `pack_conv_weights` (w then only gives the shape)."""
     lib = _lib.load()
     x = _nhwc(x)
     B, Cx, H, W = x.shape
     cout, cin, ks, _ = w.shape
+    if packed is not None:
+        if Cx != (cout if data_grad else cin):
+            raise ValueError(f"conv2d: input has {Cx} channels, weights {tuple(w.shape)}, data_grad={data_grad}")
+        mode = (2 if stride == 2 else 1) if data_grad else 0
+        co = cin if data_grad else cout
+        Ho, Wo = (2 * H, 2 * W) if mode == 2 else ((H // 2, W // 2) if stride == 2 else (H, W))
+        y = torch.empty((B, co, Ho, Wo), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        if res is not None:
+            res = _nhwc(res)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        py_, px_ = pad if pad is not None else (-1, -1)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.hh_conv2d_packed(x.data_ptr(), B, H, W, cin, packed.data_ptr(), cout, ks, stride, mode, py_, px_,
+                                            bias.data_ptr() if bias is not None else None, res.data_ptr() if res is not None else None,
+                                            int(relu), y.data_ptr(), stream))
+        return y
     w = w.detach().to(x.device, torch.float32).contiguous()
     if Cx != (cout if data_grad else cin):
         raise ValueError(f"conv2d: input has {Cx} channels, weights {tuple(w.shape)}, data_grad={data_grad}")
@@ -87,6 +104,44 @@ def bn_train_backward(x: Tensor, y: Tensor, dy: Tensor, mean: Tensor, invstd: Te
                                             g.data_ptr(), int(relu), dx.data_ptr(), dres.data_ptr() if dres is not None else None,
                                             dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(), stream))
     return dx, dgamma, dbeta, dres
+
+
+class PackedConvWeights:
+    """bf16 kernel-layout copies of a set of conv weights, all refreshed by ONE launch (`refresh`, once per training step
+    before the forward).  entries: (weight [cout,cin,ks,ks] fp32 CUDA parameter, stride, data_grad)."""
+
+    def __init__(self, entries: list):
+        import ctypes as C
+        lib = _lib.load()
+        self.n = len(entries)
+        self.buffers: list[Tensor] = []
+        self._keep = [w for w, _, _ in entries]
+        shapes = (C.c_int32 * (5 * self.n))()
+        dev = entries[0][0].device if entries else None
+        for i, (w, stride, data_grad) in enumerate(entries):
+            cout, cin, ks, _ = w.shape
+            mode = (2 if stride == 2 else 1) if data_grad else 0
+            nel = lib.hh_conv2d_packed_elems(cin, cout, ks, stride, mode)
+            if nel < 0:
+                raise _lib.HHError(f"no kernel family for conv weights {tuple(w.shape)} (stride {stride}, data_grad={data_grad})")
+            self.buffers.append(torch.empty(nel, device=dev, dtype=torch.bfloat16))
+            shapes[5 * i:5 * i + 5] = [cout, cin, ks, stride, mode]
+        self._shapes = shapes
+        self._w = (C.c_void_p * self.n)(*[w.data_ptr() for w, _, _ in entries])
+        self._p = (C.c_void_p * self.n)(*[b.data_ptr() for b in self.buffers])
+        self._descs = torch.empty(max(1, self.n) * 4 * 64, device=dev, dtype=torch.uint8) if entries else None
+
+    def pointers_current(self) -> bool:
+        return all(w.data_ptr() == p for w, p in zip(self._keep, self._w))
+
+    def refresh(self) -> None:
+        if not self.n:
+            return
+        lib = _lib.load()
+        dev = self._descs.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(lib.hh_pack_conv_weights_batch(self.n, self._w, self._p, self._shapes, self._descs.data_ptr(), stream))
 
 
 def _all_reduce_sums(sums: Tensor, group) -> None:

@@ -1,0 +1,31 @@
+"""Which aten ops / kernels does one training step launch, by count?"""
+import importlib, os, sys
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+pkg = importlib.import_module("pytorch-human-pose_amd")
+B, K, S = 4, 17, 256
+net = pkg.HigherHRNet(K, 32)
+net.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()})
+net = net.cuda().train()
+loss_fn = pkg.AEKeypointsLoss()
+opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+x = torch.from_numpy(pkg.synth.synth_images(B, S, S, 0)).cuda()
+hms, masks, joints = pkg.synth.synth_train_targets(B, K, S, 3, seed=0)
+hms = [torch.from_numpy(h).cuda() for h in hms]; masks = [torch.from_numpy(m).cuda() for m in masks]
+def step():
+    ph, pt = net(x)
+    hl, push, pull = loss_fn.calculate_loss(ph, pt, hms, masks, joints)
+    loss = hl[0] + hl[1] + push[0] + pull[0]
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+for _ in range(2): step()
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU]) as prof:
+    step()
+torch.cuda.synchronize()
+rows = sorted(prof.key_averages(), key=lambda e: -e.count)
+for e in rows[:40]:
+    print(f"{e.count:6d}  {e.key[:80]}")

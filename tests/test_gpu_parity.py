@@ -458,6 +458,7 @@ def test_training_building_blocks_conv_and_batchnorm(pkg):
         err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
         assert err < tol, (what, err)
 
+    packed_cases = []
     for (cin, cout, ks, stride, hw) in [(64, 64, 3, 1, 32), (32, 32, 3, 1, 40), (128, 64, 1, 1, 16), (64, 256, 1, 1, 24), (64, 128, 3, 2, 32), (32, 32, 3, 2, 24),
                                         (48, 48, 3, 1, 16), (256, 256, 3, 1, 16)]:
         x = _bf(torch.randn(2, cin, hw, hw, generator=g))
@@ -473,7 +474,16 @@ def test_training_building_blocks_conv_and_batchnorm(pkg):
         dy = _bf(torch.randn(2, cout, hw // stride, hw // stride, generator=g))
         F.conv2d(xr, wr, None, stride, (ks - 1) // 2).backward(dy)
         close(ops.conv2d_weight_grad(x.to(DEV, torch.bfloat16), dy.to(DEV, torch.bfloat16), ks, stride), wr.grad, ("wgrad", cin, cout, ks, stride), 5e-3)
-        close(ops.conv2d(dy.to(DEV, torch.bfloat16), w.to(DEV), stride, data_grad=True), xr.grad, ("dgrad", cin, cout, ks, stride))
+        dgrad = ops.conv2d(dy.to(DEV, torch.bfloat16), w.to(DEV), stride, data_grad=True)
+        close(dgrad, xr.grad, ("dgrad", cin, cout, ks, stride))
+        packed_cases.append((w.to(DEV), stride, x.to(DEV, torch.bfloat16), dy.to(DEV, torch.bfloat16),
+                             ops.conv2d(x.to(DEV, torch.bfloat16), w.to(DEV), stride), dgrad))
+    # weights packed ahead by ONE batched launch (hh_pack_conv_weights_batch + hh_conv2d_packed): bit-identical results
+    pw = ops.PackedConvWeights([e for w, stride, *_ in packed_cases for e in ((w, stride, False), (w, stride, True))])
+    pw.refresh()
+    for i, (w, stride, xd, dyd, fwd, dgrad) in enumerate(packed_cases):
+        assert torch.equal(ops.conv2d(xd, w, stride, packed=pw.buffers[2 * i]), fwd), ("packed fwd", tuple(w.shape), stride)
+        assert torch.equal(ops.conv2d(dyd, w, stride, data_grad=True, packed=pw.buffers[2 * i + 1]), dgrad), ("packed dgrad", tuple(w.shape), stride)
     for (C, hw, relu, with_res) in [(32, 24, True, False), (64, 16, True, True), (256, 8, False, False), (48, 12, True, True), (384, 8, True, False)]:
         x = _bf(torch.randn(3, C, hw, hw, generator=g) * 2 + 0.5).requires_grad_()
         gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
