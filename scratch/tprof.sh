@@ -12,5 +12,8 @@ import csv,glob
 f=sorted(glob.glob('gpurun_out/tprof/**/*kernel_stats.csv',recursive=True))[-1]
 rows=list(csv.DictReader(open(f))); tot=sum(float(r['TotalDurationNs']) for r in rows)
 print('kernel ms per step', tot/7e6)
-for r in rows[:16]: print(r['Name'][:60], r['Calls'], round(float(r['TotalDurationNs'])/tot*100,1), round(float(r['AverageNs'])/1e3,1))
+for r in rows[:14]: print(r['Name'][:60], r['Calls'], round(float(r['TotalDurationNs'])/tot*100,1), round(float(r['AverageNs'])/1e3,1))
+print('--- by calls per step')
+for r in sorted(rows, key=lambda r: -int(r['Calls']))[:16]: print(r['Name'][:70], int(r['Calls'])//7, round(float(r['AverageNs'])/1e3,1))
+print('launches per step', sum(int(r['Calls']) for r in rows)//7)
 "
