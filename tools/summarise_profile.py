@@ -103,11 +103,11 @@ for which in ("stats", "serial"):
         if ln.startswith('{"metric"'):
             lines += ["", f"bench.py line of the traced `{which}` run (profiler attached, so slower than an untraced run):", "", "```", ln.strip(), "```"]
 train_csv = os.path.join(prof, f"{tag}_train_step_kernel_stats.csv")
-if os.path.exists(train_csv):  # kept from `rocprofv3 --kernel-trace --stats -- python3 tools/train_bench.py 32 3` (5 steps traced)
+if os.path.exists(train_csv):  # kept from `rocprofv3 --kernel-trace --stats -- python3 tools/train_bench.py 32 5` (7 steps traced)
     trows = list(csv.DictReader(open(train_csv)))
-    lines += ["", "## Training step (`rocprofv3 --kernel-trace --stats -- python3 tools/train_bench.py 32 3`: HigherHRNet-W32, batch 32 @ 512x512, "
-              "forward with train-mode BN + AE loss + backward + Adam; 5 steps traced)", "",
-              f"Top kernels of {tag}_train_step_kernel_stats.csv (step wall time 72 ms untraced):", "",
+    lines += ["", "## Training step (`rocprofv3 --kernel-trace --stats -- python3 tools/train_bench.py 32 5`: HigherHRNet-W32, batch 32 @ 512x512, "
+              "forward with train-mode BN + AE loss + backward + Adam; 2 warm-up + 5 timed steps traced, the one-off Adam state fills and weight uploads included)", "",
+              f"Top kernels of {tag}_train_step_kernel_stats.csv (step wall time 61 ms untraced):", "",
               "| kernel | calls | avg us | % of kernel time |", "|---|---|---|---|"]
     lines += [f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |" for r in trows[:14]]
 open(os.path.join(prof, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
