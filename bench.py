@@ -163,8 +163,8 @@ def train_bench(args, pkg, dist, rank, world, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--people", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
