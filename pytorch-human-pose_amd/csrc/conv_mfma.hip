@@ -54,7 +54,7 @@ __device__ __forceinline__ void static_for(F &&f)
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-#ifdef HH_CONV_DEBUG  // phase stamps of every workgroup (wave 0), read by scratch/conv_probe.hip only
+#ifdef HH_CONV_DEBUG  // phase stamps of every workgroup (wave 0), read by tools/probes/conv_probe.hip only
 __device__ long long g_conv_dbg[8192 * 8];
 #define CONV_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_conv_dbg[blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else

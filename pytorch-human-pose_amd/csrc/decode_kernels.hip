@@ -119,7 +119,7 @@ __device__ __forceinline__ unsigned short bf16_ceil(float f)
 // global store it has issued (cell maxima, candidate lists) is acknowledged by memory: a full round trip per barrier that no
 // thread of the workgroup depends on.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#ifdef HH_NMS_DEBUG  // phase stamps of a sample of workgroups, read by scratch/nms_probe.hip only
+#ifdef HH_NMS_DEBUG  // phase stamps of a sample of workgroups, read by tools/probes/nms_probe.hip only
 __device__ long long g_nms_dbg[4096 * 8];
 #define NMS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x >= 8192 && blockIdx.x < 8192 + 4096) g_nms_dbg[(blockIdx.x - 8192) * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else

@@ -1,7 +1,7 @@
 // One-off probe: phase timestamps inside conv_mfma_kernel (hipcc -DHH_CONV_DEBUG, includes the kernel source).
 // usage: conv_probe C HW [cfg]   (3x3 stride-1 conv, C -> C channels on a B=32 x HW x HW map, residual + ReLU)
 #define HH_CONV_DEBUG 1
-#include "../pytorch-human-pose_amd/csrc/conv_mfma.hip"
+#include "../../pytorch-human-pose_amd/csrc/conv_mfma.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

@@ -1,6 +1,6 @@
 // One-off probe: phase timestamps inside nms_tile_topk_kernel (hipcc -DHH_NMS_DEBUG, includes the kernel source).
 #define HH_NMS_DEBUG 1
-#include "../pytorch-human-pose_amd/csrc/decode_kernels.hip"
+#include "../../pytorch-human-pose_amd/csrc/decode_kernels.hip"
 #include <cstdio>
 #include <vector>
 #include <algorithm>

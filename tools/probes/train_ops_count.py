@@ -1,7 +1,7 @@
 """Which aten ops / kernels does one training step launch, by count?"""
 import importlib, os, sys
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 pkg = importlib.import_module("pytorch-human-pose_amd")
 B, K, S = 4, 17, 256
