@@ -231,6 +231,9 @@ def test_decode_degenerate_and_edge_inputs(pkg, synth):
     # a large, non-square map: 768 x 1024 model input (tiles straddle the border in y: 768 = 12 tiles, 1024 = 16)
     a, b, t, _ = synth.synth_decode_maps(K, 192, 256, 6, seed=70)
     _decode_both(pkg, a, b, t, K)
+    # 64 joints x 2 embedding dimensions: the matching kernel's candidate tables no longer fit its LDS staging (global path)
+    a, b, t, _ = synth.synth_decode_maps(64, 24, 24, 3, seed=80, emb=2)
+    _decode_both(pkg, a, b, t, 64)
     # 244 x 244: the last NMS tile of a row / column is 4 pixels wide, the corner tile 4 x 4 (fewer pixels than top-k entries)
     a, b, t, _ = synth.synth_decode_maps(K, 61, 61, 3, seed=71)
     _decode_both(pkg, a, b, t, K)
