@@ -110,6 +110,10 @@ if os.path.exists(train_csv):  # kept from `rocprofv3 --kernel-trace --stats -- 
               f"Top kernels of {tag}_train_step_kernel_stats.csv (step wall time 61 ms untraced):", "",
               "| kernel | calls | avg us | % of kernel time |", "|---|---|---|---|"]
     lines += [f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |" for r in trows[:14]]
+probes = [f for f in (f"{tag}_conv_probe.txt", f"{tag}_nms_probe.txt", f"{tag}_dispatch_probe.txt") if os.path.exists(os.path.join(prof, f))]
+if probes:  # probe outputs (tools/probes/build.sh; kernel sources compiled with phase stamps)
+    lines += ["", "## Kernel-internal probes", "", "Phase stamps inside the kernels (s_memtime per workgroup), start skew and inter-launch gaps: " +
+              ", ".join(f"`{f}`" for f in probes) + " (built by `tools/probes/build.sh`, see DESIGN.md section 6)."]
 open(os.path.join(prof, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 
 # per-launch HBM bytes keyed the way bench.py names kernels
