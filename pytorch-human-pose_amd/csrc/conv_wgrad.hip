@@ -33,28 +33,45 @@ __device__ __forceinline__ i16x4 tr_read(const char *lds, int byte_off)
 }
 }  // namespace
 
-template <int KS, int S, int TW>
+// NTG = taps per workgroup: the 9 taps of a 3x3 kernel are split over two workgroups (5 + 4, blockIdx.z) that stage the same
+// tiles (the second read comes from L2) and write disjoint parts of the worker's partial sums.  That doubles the workgroups
+// (one per CU was all a 64-channel layer had: every extra pixel-range worker costs a 9 x 64 x 64 partial set the reduction
+// reads back) and takes the accumulators from 144 to 80 registers.
+// SMALLC (cin, cout <= 32, the highest-resolution branch and the deconv head): the 64 x 64 channel block would leave three
+// of the four waves multiplying padding, so there every wave takes the one real 32 x 32 block and the waves split the
+// TAPS instead (wave w: taps w, w+4, w+8).
+template <int KS, int S, int TW, int NTG, bool SMALLC>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 {
     constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, NTAP = KS * KS;
+    const int tap0 = SMALLC ? (int)(threadIdx.x >> 6) : blockIdx.z * NTG;  // first tap of this wave ...
+    constexpr int TSTEP = SMALLC ? 4 : 1;                                   // ... and the stride to its next ones
     constexpr int Y_UNITS = TH * TW * 8, X_UNITS = PH * PW * 8;          // 16-byte units (8 per 64-channel pixel)
     constexpr int NYL = (Y_UNITS + 255) / 256, NXL = (X_UNITS + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ldsY = smem, *ldsX = smem + TH * TW * RS;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tco = wave >> 1, tci = wave & 1;
+    const int tco = SMALLC ? 0 : wave >> 1, tci = SMALLC ? 0 : wave & 1;
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, hh = g >> 1;
     const int ncib = (p.cin + 63) / 64;
     const int co0 = (blockIdx.y / ncib) * 64, ci0 = (blockIdx.y % ncib) * 64;  // channel block of this workgroup
     const int pad_y = p.pad_y, pad_x = p.pad_x;
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH, ntiles = p.B * tiles_y * tiles_x;
 
-    f32x16 acc[NTAP];
+    f32x16 acc[NTG];
 #pragma unroll
-    for (int t = 0; t < NTAP; ++t)
+    for (int t = 0; t < NTG; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    // X-patch offset (pixels) of this workgroup's taps; a group short of NTG taps repeats its last one (computed, not stored:
+    // no branch inside the pipelined loop)
+    int tapoff[NTG];
+#pragma unroll
+    for (int t = 0; t < NTG; ++t) {
+        const int tap = min(tap0 + t * TSTEP, NTAP - 1);
+        tapoff[t] = (tap / KS) * PW + tap % KS;
+    }
 
     // byte offsets of this lane's transposed reads inside a tile (row part added per k-step)
     const int ycol = (tco * 32 + 16 * (g & 1) + 4 * pp) * 2, xcol = (tci * 32 + 16 * (g & 1) + 4 * pp) * 2;
@@ -90,10 +107,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             xmask |= ok ? (1u << i) : 0u;
         });
     };
+    if ((int)blockIdx.x < ntiles) issue_loads(blockIdx.x);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        // (prefetching the next tile across the MFMA loop was measured: no gain, and its 44 live registers push the
-        //  pipelined loop below into scratch; two workgroups per CU cover each other's load latency instead)
-        issue_loads(t);
         __syncthreads();  // the previous tile's reads are done
         sfor<NYL>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -106,10 +121,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             if (u < X_UNITS) *reinterpret_cast<u32x4 *>(ldsX + (u >> 3) * RS + (u & 7) * 16) = (xmask >> i) & 1u ? xreg[i] : u32x4{0u, 0u, 0u, 0u};
         });
         __syncthreads();
+        // the next tile's loads fly under this tile's MFMAs (the staging registers are free once they are in LDS; with the
+        // taps split over two workgroups the 44 of them fit beside 80 accumulator registers)
+        issue_loads(t + gridDim.x);
         // ---- contraction over the tile's pixels, 16 per MFMA k-step (one half row of TW = 32, or a row of TW = 16)
         // Flat software pipeline over (k-step, tap): the transposed reads of step i+1 are issued before the MFMA of step i
         // (sched_group_barrier pins that order), so an MFMA never waits on the LDS latency of its own operands.
-        constexpr int NKS = TH * (TW / 16), NSTEP = NKS * NTAP;
+        constexpr int NKS = TH * (TW / 16), NSTEP = NKS * NTG;
         i16x8 afrag[2], bfrag[2];
         auto ld_a = [&](int ks, int buf) {
             const int y = ks / (TW / 16), hx = ks % (TW / 16);
@@ -118,9 +136,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             afrag[buf] = i16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         };
         auto ld_b = [&](int step, int buf) {
-            const int ks = step / NTAP, tap = step % NTAP, ky = tap / KS, kx = tap % KS;
+            const int ks = step / NTG, tap = step % NTG;
             const int y = ks / (TW / 16), hx = ks % (TW / 16);
-            const int xrow = (y * S + ky) * PW + (hx * 16 + 8 * hh + q) * S + kx;
+            const int xrow = (y * S) * PW + (hx * 16 + 8 * hh + q) * S + tapoff[tap];
             const i16x4 b0 = tr_read(ldsX, xrow * RS + xcol), b1 = tr_read(ldsX, (xrow + 4 * S) * RS + xcol);
             bfrag[buf] = i16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
         };
@@ -128,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         ld_b(0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         sfor<NSTEP>([&](auto sc) {
-            constexpr int step = decltype(sc)::value, ks = step / NTAP, tap = step % NTAP;
-            constexpr bool next_a = step + 1 < NSTEP && (step + 1) % NTAP == 0;
+            constexpr int step = decltype(sc)::value, ks = step / NTG, tap = step % NTG;
+            constexpr bool next_a = step + 1 < NSTEP && (step + 1) % NTG == 0;
             if constexpr (step + 1 < NSTEP) ld_b(step + 1, (step + 1) & 1);
             if constexpr (next_a) ld_a(ks + 1, (ks + 1) & 1);
             if constexpr (step + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, next_a ? 4 : 2, 0);
@@ -143,14 +161,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int coutp = (p.cout + 63) / 64 * 64, cinp = ncib * 64;
     float *part = p.partial + (size_t)blockIdx.x * NTAP * coutp * cinp;
 #pragma unroll
-    for (int tap = 0; tap < NTAP; ++tap)
+    for (int t = 0; t < NTG; ++t)
+        if (tap0 + t * TSTEP < NTAP)
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg)
+            for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int co = co0 + tco * 32 + 8 * gg + 4 * h + i, ci = ci0 + tci * 32 + r32;
-                part[((size_t)tap * coutp + co) * cinp + ci] = acc[tap][4 * gg + i];
-            }
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + tco * 32 + 8 * gg + 4 * h + i, ci = ci0 + tci * 32 + r32;
+                    part[((size_t)(tap0 + t * TSTEP) * coutp + co) * cinp + ci] = acc[t][4 * gg + i];
+                }
 }
 
 // dW[co][ci][tap] = sum over workgroups (fixed order) of part[wg][tap][co][ci], in two stages so that the column sums of
@@ -192,12 +211,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float *__restr
     }
 }
 
-template <int KS, int S, int TW>
+template <int KS, int S, int TW, bool SMALLC = false>
 static hipError_t launch_one(const WgradParams &p, int nwg, hipStream_t s)
 {
     constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
+    constexpr int NTG = SMALLC ? (KS * KS + 3) / 4 : (KS == 3 ? 5 : KS * KS), NGRP = SMALLC ? 1 : (KS * KS + NTG - 1) / NTG;
     const size_t lds = (size_t)(TH * TW + PH * PW) * RS;
-    auto fn = conv_wgrad_kernel<KS, S, TW>;
+    auto fn = conv_wgrad_kernel<KS, S, TW, NTG, SMALLC>;
     static bool configured = false;  // once per instantiation
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -205,7 +225,7 @@ static hipError_t launch_one(const WgradParams &p, int nwg, hipStream_t s)
         configured = true;
     }
     const int ncob = (p.cout + 63) / 64, ncib = (p.cin + 63) / 64;
-    hipLaunchKernelGGL(fn, dim3(nwg, ncob * ncib), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(fn, dim3(nwg, ncob * ncib, NGRP), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -227,6 +247,7 @@ hipError_t conv_wgrad_launch(const WgradParams &p, int ks, int stride, float *dw
     const int nwg = conv_wgrad_num_workers(p.B, p.Ho, p.Wo, stride, p.cin, p.cout);
     hipError_t e = hipErrorInvalidValue;
     if (ks == 3 && stride == 1 && p.Wo <= 16) e = launch_one<3, 1, 16>(p, nwg, s);  // narrow maps: no half-empty tiles
+    else if (ks == 3 && stride == 1 && p.cin <= 32 && p.cout <= 32) e = launch_one<3, 1, 32, true>(p, nwg, s);
     else if (ks == 3 && stride == 1) e = launch_one<3, 1, 32>(p, nwg, s);
     else if (ks == 1 && stride == 1) e = launch_one<1, 1, 32>(p, nwg, s);
     else if (ks == 3 && stride == 2) e = launch_one<3, 2, 16>(p, nwg, s);
