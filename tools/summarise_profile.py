@@ -107,7 +107,7 @@ if os.path.exists(train_csv):  # kept from `rocprofv3 --kernel-trace --stats -- 
     trows = list(csv.DictReader(open(train_csv)))
     lines += ["", "## Training step (`rocprofv3 --kernel-trace --stats -- python3 tools/train_bench.py 32 5`: HigherHRNet-W32, batch 32 @ 512x512, "
               "forward with train-mode BN + AE loss + backward + Adam; 2 warm-up + 5 timed steps traced, the one-off Adam state fills and weight uploads included)", "",
-              f"Top kernels of {tag}_train_step_kernel_stats.csv (step wall time 61 ms untraced):", "",
+              f"Top kernels of {tag}_train_step_kernel_stats.csv (step wall time 60 ms untraced):", "",
               "| kernel | calls | avg us | % of kernel time |", "|---|---|---|---|"]
     lines += [f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |" for r in trows[:14]]
 probes = [f for f in (f"{tag}_conv_probe.txt", f"{tag}_nms_probe.txt", f"{tag}_dispatch_probe.txt") if os.path.exists(os.path.join(prof, f))]
