@@ -119,8 +119,11 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fused_kernel(const BBParams p)
     int pl_off[NPL], pl_yx[NPL];  // prefetch unit i: element offset from the tile's patch origin, (py << 8) | px
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-        const int u = tid + NTHR * i, pix = u >> 2, py = pix / IW, px = pix % IW;
-        pl_off[i] = (py * p.W + px) * p.in_cs + (u & 3) * 8;
+        // unit u -> (pixel, 16-byte part): 16 consecutive lanes take the SAME part of 16 consecutive pixels, so that a
+        // quarter-wave of ds_write_b128 (16 lanes x 16 B at the 80-byte pixel stride) touches every bank once; with the four
+        // parts of a pixel on neighbouring lanes the pixels 0 and 3 of a quarter collided (2-way conflict on every patch write)
+        const int u = tid + NTHR * i, pix = (u >> 6) * 16 + (u & 15), part = (u >> 4) & 3, py = pix / IW, px = pix % IW;
+        pl_off[i] = (py * p.W + px) * p.in_cs + part * 8;
         pl_yx[i] = u < P_UNITS ? ((py << 8) | px) : (255 << 8);  // py = 255 -> never inside
     }
     // conv1 column tiles: waves 0-3 own 3 each (tiles 3w..3w+2), waves 4-7 own 2 each (12+2(w-4)..): waves w and w+4 share a
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fused_kernel(const BBParams p)
     auto write_patch_unit = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int u = tid + NTHR * i;  // units >= P_UNITS land in the pad behind the patch
-        *reinterpret_cast<u32x4 *>(lds_p + (u >> 2) * PS + (u & 3) * 16) = (pf_mask >> i) & 1u ? preg[i] : u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4 *>(lds_p + ((u >> 6) * 16 + (u & 15)) * PS + ((u >> 4) & 3) * 16) = (pf_mask >> i) & 1u ? preg[i] : u32x4{0u, 0u, 0u, 0u};
     };
     // Workgroup barrier that waits for LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would stall every
     // wave until the next tile's prefetch loads (issued during conv1, consumed during conv2) and the previous tile's
