@@ -166,8 +166,8 @@ int hh_loss_ae_grouping(const float *tags, int64_t tags_bstride, const int32_t *
                         int h, int w, float *push_pull, float *grad, int64_t grad_bstride, float push_scale, float pull_scale,
                         double *scratch, void *stream);
 
-/* Building blocks of the training step (keypoints/module.py:43-71; not yet assembled into a net: conv weight gradients,
- * stride-2 data gradients and the optimizer are missing).  Activations are NHWC bf16 [B,H,W,C] (= torch channels_last),
+/* Building blocks of the training step (keypoints/module.py:43-71), assembled into the net's training forward / backward
+ * by keypoints/train_net.py with torch autograd as the tape.  Activations are NHWC bf16 [B,H,W,C] (= torch channels_last),
  * parameters fp32, all device pointers.
  *
  * hh_conv2d: y = act(conv(x, w) + bias (+ res)) with the CURRENT fp32 weights w [cout][cin][ks][ks] (packed on the device

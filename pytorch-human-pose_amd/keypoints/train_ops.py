@@ -1,5 +1,5 @@
 """Python face of the training building blocks (`hh_conv2d`, `hh_bn_train_*`): NHWC bf16 activations as torch tensors
-in channels_last memory format, fp32 parameters.  Not yet assembled into a trainable net."""
+in channels_last memory format, fp32 parameters.  `train_net.py` assembles them into the net's training forward."""
 from __future__ import annotations
 
 import torch
