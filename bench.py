@@ -185,7 +185,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if os.environ.get("HH_BENCH_REHEARSAL"):
+            # rehearsal of the N > 1 code path on a ONE-GPU box (every rank on cuda:0, gloo): checks the launch contract
+            # (barriers, max over ranks, rank-0 line), not performance - the driver's multi-GPU runs use RCCL below
+            local_rank = 0
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     pkg = importlib.import_module(PKG)
