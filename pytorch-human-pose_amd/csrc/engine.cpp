@@ -535,7 +535,16 @@ int hh_net::finalize()
     for (auto &g : graphs) hipGraphExecDestroy(g.exec);
     graphs.clear();
     for (int l = 1; l < 4; ++l)
-        if (!lane_streams[l]) HH_CHECK_HIP(hipStreamCreateWithFlags(&lane_streams[l], hipStreamNonBlocking));
+        if (!lane_streams[l]) {
+            // highest priority: on this stack the dependent launches of a high-priority queue follow each other noticeably
+            // faster (forward alone 5.25 -> 4.93 ms, bench +5 % with the caller's streams at the same priority);
+            // HH_LANE_PRIORITY=0 restores default-priority lanes for A/B runs
+            int least = 0, greatest = 0;
+            HH_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            static const char *env = getenv("HH_LANE_PRIORITY");
+            const int prio = env ? atoi(env) : greatest;
+            HH_CHECK_HIP(hipStreamCreateWithPriority(&lane_streams[l], hipStreamNonBlocking, prio));
+        }
     finalized = true;
     return 0;
 }
