@@ -534,17 +534,6 @@ int hh_net::finalize()
     }
     for (auto &g : graphs) hipGraphExecDestroy(g.exec);
     graphs.clear();
-    for (int l = 1; l < 4; ++l)
-        if (!lane_streams[l]) {
-            // highest priority: on this stack the dependent launches of a high-priority queue follow each other noticeably
-            // faster (forward alone 5.25 -> 4.93 ms, bench +5 % with the caller's streams at the same priority);
-            // HH_LANE_PRIORITY=0 restores default-priority lanes for A/B runs
-            int least = 0, greatest = 0;
-            HH_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            static const char *env = getenv("HH_LANE_PRIORITY");
-            const int prio = env ? atoi(env) : greatest;
-            HH_CHECK_HIP(hipStreamCreateWithPriority(&lane_streams[l], hipStreamNonBlocking, prio));
-        }
     finalized = true;
     return 0;
 }
@@ -621,6 +610,21 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
     // on separate HIP streams (forked from / joined to the caller's stream with events; the same calls become
     // DAG edges under hipGraph capture).  The small low-resolution launches then fill CUs the big ones leave idle.
     const bool multi = multi_lane && !taps_enabled && !prof_enabled;
+    if (multi) {
+        // The lanes take the PRIORITY of the caller's stream.  A caller on a highest-priority stream gets its whole forward
+        // on high-priority queues (dependent launches follow each other faster there: forward 5.25 -> 4.98 ms at batch 32),
+        // while lanes above the caller's own priority made the fork/join pattern erratic (1.8 -> 5.9 ms at batch 1).
+        int prio = 0;
+        HH_CHECK_HIP(hipStreamGetPriority(s0, &prio));
+        if (!lane_priority_set || prio != lane_priority) {
+            for (int l = 1; l < 4; ++l) {
+                if (lane_streams[l]) { HH_CHECK_HIP(hipStreamSynchronize(lane_streams[l])); HH_CHECK_HIP(hipStreamDestroy(lane_streams[l])); }
+                HH_CHECK_HIP(hipStreamCreateWithPriority(&lane_streams[l], hipStreamNonBlocking, prio));
+            }
+            lane_priority = prio;
+            lane_priority_set = true;
+        }
+    }
     hipStream_t L[4] = {s0, multi ? lane_streams[1] : s0, multi ? lane_streams[2] : s0, multi ? lane_streams[3] : s0};
     lane_events_used = 0;
     auto next_event = [&](hipEvent_t *e) -> int {

@@ -117,6 +117,8 @@ struct hh_net {
     double clk_khz = 0;                   // hipDeviceAttributeWallClockRate
     // lanes 1..3: internal streams forked from / joined to the caller's stream (also inside hipGraph capture)
     hipStream_t lane_streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    int lane_priority = 0;           // the lanes always share the priority of the caller's stream (see enqueue)
+    bool lane_priority_set = false;
     std::vector<hipEvent_t> lane_events;
     size_t lane_events_used = 0;
     bool multi_lane = true;

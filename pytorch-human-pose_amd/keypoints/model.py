@@ -147,6 +147,7 @@ class InferenceKeypointsModel:
         self._lib = _lib.load()
         self._parser = MPPEHeatmapParser(net.num_kpts, max_num_people, det_thr, tag_thr)
         self._perm = np.asarray(COCO_FLIP_INDEX, np.int32)
+        self._stream = None
         if ckpt_path is not None:
             self.load_checkpoint(ckpt_path)
 
@@ -249,10 +250,25 @@ class InferenceKeypointsModel:
         hms, tags = self.forward_tta(x)
         return self._parser.decode_batch_device(hms[0], hms[1], tags, adjust=True, refine=True)
 
+    def _on_fast_stream(self, fn):
+        """Run `fn` on this model's highest-priority stream, ordered after / before the caller's current stream.  A single
+        image is a chain of ~350 small dependent launches; on this stack they follow each other faster on a high-priority
+        queue (the engine's branch lanes take the priority of the stream they are forked from)."""
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(self.device, priority=torch.cuda.Stream.priority_range()[1])
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            out = fn()
+        cur.wait_stream(self._stream)
+        return out
+
     def __call__(self, raw_image: np.ndarray, annot: list | None) -> InferenceKeypointsResult:
         """model.py:78-111"""
-        x, center, scale = self.prepare_input(raw_image)
-        self.model_input_shape = tuple(x.shape[-2:])
-        hms, tags = self.forward_tta(x)
-        return InferenceKeypointsResult.from_preds(raw_image, annot, x[0], hms, tags, self.limbs, scale, center, self.det_thr,
-                                                   self.tag_thr, self.max_num_people, parser=self._parser)
+        def run():
+            x, center, scale = self.prepare_input(raw_image)
+            self.model_input_shape = tuple(x.shape[-2:])
+            hms, tags = self.forward_tta(x)
+            return InferenceKeypointsResult.from_preds(raw_image, annot, x[0], hms, tags, self.limbs, scale, center, self.det_thr,
+                                                       self.tag_thr, self.max_num_people, parser=self._parser)
+        return self._on_fast_stream(run)
