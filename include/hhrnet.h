@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define HH_ABI_VERSION 1
+#define HH_ABI_VERSION 2
 #define HH_DTYPE_BF16 1 /* bf16 MFMA operands, fp32 accumulate, bf16 NHWC activations */
 
 typedef struct hh_net hh_net;
@@ -139,16 +139,22 @@ int hh_decoder_reserve(hh_decoder *dec, int B, int H, int W, int E); /* H, W = f
  *   hm_h   [B,K,2hq,2wq] fp32
  *   tags_q E pointers (host array of device pointers), each [B,K,hq,wq]
  * Outputs (device): joints [B,max_people,K,3+E] (x, y, score, tag...; zero rows = no person),
- * scores [B,max_people], num_people [B].  Bit-exact with the reference on identical inputs
- * (ties between equal candidate scores are ordered by ascending pixel index).           */
+ * scores [B,max_people], num_people [B], flags [B] (may be NULL).  Bit-exact with the reference on identical inputs
+ * (ties between equal candidate scores are ordered by ascending pixel index).
+ * flags[b] bits: HH_DECODE_FALLBACK = no group was formed and the one person returned is the best-candidate pseudo-person
+ * of grouping.py:262-269 (the reference's arrays are float64 there with the score 0.01 as a double; the device arrays stay
+ * float32 and the host shim widens them); HH_DECODE_SOLVER_GUARD = the assignment solver stopped at its iteration guard,
+ * the image's result is invalid and the caller must raise.                                                           */
+#define HH_DECODE_FALLBACK 1
+#define HH_DECODE_SOLVER_GUARD 2
 int hh_decode(hh_decoder *dec, const float *hm_q, int64_t hm_q_bstride, const float *hm_h, int64_t hm_h_bstride,
               const float *const *tags_q, const int64_t *tags_bstride, int E, int B, int hq, int wq, int adjust,
-              int refine, float *joints, float *scores, int32_t *num_people, void *stream);
+              int refine, float *joints, float *scores, int32_t *num_people, int32_t *flags, void *stream);
 
 /* MPPEHeatmapParser.parse on explicit full-resolution maps (grouping.py:252-283):
  *   hm_full [B,K,H,W] fp32, tags_full [B,K,H,W,E] fp32 (both contiguous).              */
 int hh_parse(hh_decoder *dec, const float *hm_full, const float *tags_full, int E, int B, int H, int W, int adjust,
-             int refine, float *joints, float *scores, int32_t *num_people, void *stream);
+             int refine, float *joints, float *scores, int32_t *num_people, int32_t *flags, void *stream);
 
 /* Training loss of keypoints/loss.py, each fused with its gradient (all pointers device memory, fp32).
  * `scratch`: >= max(1024, 2*B) doubles.  Sums are taken in double in a fixed order (results do not depend on the launch).

@@ -120,6 +120,10 @@ def parse(hm_full, tags_full, max_people=30, det_thr=0.1, tag_thr=1.0, adjust=Tr
     P = lib().orc_parse(_p(hm_full, C.c_float), _p(tags_full, C.c_float), K, H, W, E, max_people, C.c_double(det_thr),
                         C.c_double(tag_thr), int(adjust), int(refine), _p(joints, C.c_float), _p(scores, C.c_float),
                         _p(tags_k, C.c_float), _p(coords_k, C.c_int32), _p(scores_k, C.c_float))
+    if P < 0:  # no group: grouping.py:262-269 builds the pseudo-person by concatenating int32 with float32 -> float64 arrays,
+        joints = joints[:1].astype(np.float64)  # writes the Python float 0.01 as its score and averages that in float64
+        joints[..., 2] = 0.01
+        scores, P = joints[..., 2].mean(1), 1
     if return_topk:
         return joints[:P], scores[:P], (tags_k, coords_k, scores_k)
     return joints[:P], scores[:P]

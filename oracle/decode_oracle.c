@@ -400,7 +400,9 @@ void orc_refine_person(float *pj, int K, int E, const float *hm_full, const floa
     }
 }
 
-/* grouping.py:252-283. joints [maxp][K][3+E], scores [maxp]; returns P (>= 1). */
+/* grouping.py:252-283. joints [maxp][K][3+E], scores [maxp]; returns P (>= 1), or -1 when no group was formed and the
+   result is the one pseudo-person of grouping.py:262-269 (the reference's arrays are float64 there: its concatenate mixes
+   int32 coordinates with float32 scores, and the score becomes the double 0.01 -- oracle/decode.py widens accordingly). */
 int orc_parse(const float *hm_full, const float *tags_full, int K, int H, int W, int E, int maxp, double det_thr,
               double tag_thr, int adjust, int refine, float *joints, float *scores,
               float *tags_k_out, int32_t *coords_k_out, float *scores_k_out)
@@ -414,6 +416,7 @@ int orc_parse(const float *hm_full, const float *tags_full, int K, int H, int W,
     orc_topk(nms, tags_full, K, H, W, E, maxp, tags_k, coords_k, scores_k);
     free(nms);
     int P = orc_match_by_tag(tags_k, coords_k, scores_k, K, maxp, E, det_thr, tag_thr, joints);
+    const int fallback = P == 0;
     if (P == 0) { /* grouping.py:262-269: best candidate per joint, score forced to 0.01 */
         for (int k = 0; k < K; ++k) {
             float *j = joints + k * D;
@@ -432,7 +435,7 @@ int orc_parse(const float *hm_full, const float *tags_full, int K, int H, int W,
     if (!tags_k_out) free(tags_k);
     if (!coords_k_out) free(coords_k);
     if (!scores_k_out) free(scores_k);
-    return P;
+    return fallback ? -P : P;
 }
 
 /* ---------------------------------------------------------------- coordinate un-warp */

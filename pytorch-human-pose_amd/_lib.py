@@ -66,8 +66,8 @@ def _sig(lib):
         "hh_decoder_create": (vp, [i32, i32, dbl, dbl]),
         "hh_decoder_destroy": (None, [vp]),
         "hh_decoder_reserve": (i32, [vp, i32, i32, i32, i32]),
-        "hh_decode": (i32, [vp, vp, i64, vp, i64, vp, pi64, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
-        "hh_parse": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+        "hh_decode": (i32, [vp, vp, i64, vp, i64, vp, pi64, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+        "hh_parse": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
         "hh_debug_check_plan": (i32, [vp]),
         "hh_loss_heatmaps": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, i64, vp, vp]),
         "hh_loss_ae_grouping": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, vp, i64, C.c_float, C.c_float, vp, vp]),
@@ -106,13 +106,26 @@ def load() -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(SO):
-            try:
-                build()
-            except Exception as e:  # noqa: BLE001
-                raise HHError(f"{SO} is missing and could not be built ({e}); run __graft_entry__.build()") from e
+            # Normally __graft_entry__.build() has produced the library.  As a convenience a missing one is built here, under an
+            # exclusive file lock so that the ranks of a torchrun launch do not compile into the same tree at once (the first
+            # holder builds, the others find the finished file), and never once this process has touched the GPU (a compiler
+            # child process next to a live HIP context is what the GPU boxes forbid under rocprofv3).
+            import fcntl
+            import torch
+            if torch.cuda.is_initialized():
+                raise HHError(f"{SO} is missing; run __graft_entry__.build() before any GPU work")
+            with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    if not os.path.exists(SO):
+                        build()
+                except Exception as e:  # noqa: BLE001
+                    raise HHError(f"{SO} is missing and could not be built ({e}); run __graft_entry__.build()") from e
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
         lib = C.CDLL(SO)
         _sig(lib)
-        if lib.hh_abi_version() != 1:
+        if lib.hh_abi_version() != 2:
             raise HHError("libhhrnet.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -353,12 +353,15 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fused_kernel(const BBParams p)
 #endif
 }
 
-static bf16_raw *g_trash = nullptr;  // 64 B every lane may scribble on (stores of lanes outside the image)
+static bf16_raw *g_trash_dev[64] = {};  // per device: 64 B every lane may scribble on (stores of lanes outside the image)
 
 hipError_t bb_fused_init()
 {
-    if (!g_trash) {
-        hipError_t e = hipMalloc((void **)&g_trash, 256);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!g_trash_dev[dev & 63]) {
+        e = hipMalloc((void **)&g_trash_dev[dev & 63], 256);
         if (e != hipSuccess) return e;
     }
     return hipFuncSetAttribute(reinterpret_cast<const void *>(bb_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -370,7 +373,9 @@ hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s)
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
-    p.trash = g_trash;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || !g_trash_dev[dev & 63]) return hipErrorNotInitialized;
+    p.trash = g_trash_dev[dev & 63];
     const int grid = p.ntiles < num_cus ? p.ntiles : num_cus;
     hipLaunchKernelGGL(bb_fused_kernel, dim3(grid), dim3(NTHR), bb_fused_lds_bytes(), s, p);
     return hipGetLastError();

@@ -217,8 +217,11 @@ static int conv2d_impl(const void *x, int B, int H, int W, int cin, const float 
     hipStream_t s = (hipStream_t)stream;
     // the kernel reads coutp bias values: an all-zero device array serves the bias-free case (no memset per call), a bias
     // whose length is already a multiple of 32 is used in place, anything else is copied behind the packed weights
-    static float *zeros = nullptr;
+    static float *zeros_dev[64] = {};  // one per device: a process may drive several GPUs
     if (!bias && coutp <= 4096) {
+        int dev = 0;
+        HH_CHECK_HIP(hipGetDevice(&dev));
+        float *&zeros = zeros_dev[dev & 63];
         if (!zeros) { HH_CHECK_HIP(hipMalloc((void **)&zeros, 4096 * 4)); HH_CHECK_HIP(hipMemset(zeros, 0, 4096 * 4)); }
         zbias = zeros;
     } else if (bias && co == coutp) {
@@ -396,11 +399,10 @@ int hh_flip_merge(float *hm, int64_t hm_bstride, const float *hm_flipped, int64_
                   int w, void *stream)
 {
     if (K > 64) { hh_set_error("hh_flip_merge: K > 64"); return 1; }
-    static thread_local int32_t *d_perm = nullptr;
-    if (!d_perm) HH_CHECK_HIP(hipMalloc((void **)&d_perm, 64 * sizeof(int32_t)));
-    HH_CHECK_HIP(hipMemcpyAsync(d_perm, perm_host, K * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+    for (int k = 0; k < K; ++k)
+        if (perm_host[k] < 0 || perm_host[k] >= K) { hh_set_error("hh_flip_merge: perm is not a permutation of 0..K-1"); return 1; }
     HH_CHECK_HIP(launch_flip_merge(hm, hm_bstride, hm_flipped, hmf_bstride, tags_flipped, tf_bstride, tags_out, to_bstride,
-                                   d_perm, B, K, h, w, (hipStream_t)stream));
+                                   perm_host, B, K, h, w, (hipStream_t)stream));
     return 0;
 }
 

@@ -7,6 +7,8 @@
 
 #define HH_MAX_EMB 4
 #define HH_MAX_PEOPLE 32  // one wave column per candidate / group in the matching kernel
+#define HH_DECODE_FALLBACK 1      // flags[b]: no group was formed, the one person is the pseudo-person of grouping.py:262-269
+#define HH_DECODE_SOLVER_GUARD 2  // flags[b]: the assignment solver hit its iteration guard (result invalid)
 #define HH_NMS_TILE 60  // + the 2-pixel halo of the 5x5 maximum = 64 = one wave of columns
 
 // Where the full-resolution maps come from.
@@ -36,7 +38,7 @@ hipError_t launch_topk_merge(const DecodeSrc &src, int M, int ntiles, unsigned l
                              float *tags_k, int32_t *coords_k, float *scores_k, hipStream_t s);
 // per image: match_by_tag (+ the "no group" fallback); joints [B,M,K,3+E], num_people [B]
 hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const float *scores_k, int B, int K, int M, int E,
-                        double det_thr, double tag_thr, float *joints, int32_t *num_people, float *ws_tags, int32_t *status,
+                        double det_thr, double tag_thr, float *joints, int32_t *num_people, float *ws_tags, int32_t *flags,
                         hipStream_t s);
 // per image: quarter-pixel adjust (optional) and person scores
 hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, float *joints, const int32_t *num_people, float *scores,

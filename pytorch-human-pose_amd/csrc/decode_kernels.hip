@@ -649,7 +649,7 @@ __constant__ int c_joints_order[17] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 7, 8, 9, 10,
 __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const int32_t *coords_k, const float *scores_k, int K, int M, int E,
                                                    double det_thr,
                                                    double tag_thr, float *__restrict__ joints, int32_t *__restrict__ num_people,
-                                                   float *__restrict__ ws_tags, int32_t *__restrict__ status, int stage)
+                                                   float *__restrict__ ws_tags, int32_t *__restrict__ flags, int stage)
 {
     __shared__ MatchShared S;
     extern __shared__ float staged[];  // the image's candidates and group tag lists, when they fit (stage != 0)
@@ -801,20 +801,21 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
                 for (int e = 0; e < E; ++e) { const float t = tags_k[(k * M) * E + e]; jr[3 + e] = (t != t) ? 0.f : t; }
             }
             P = 1;
+            bad |= HH_DECODE_FALLBACK << 8;
         }
         num_people[b] = P;
-        if (bad) atomicOr(status, 1);
+        flags[b] = ((bad >> 8) & HH_DECODE_FALLBACK) | ((bad & 0xff) ? HH_DECODE_SOLVER_GUARD : 0);
     }
 }
 
 hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const float *scores_k, int B, int K, int M, int E,
-                        double det_thr, double tag_thr, float *joints, int32_t *num_people, float *ws_tags, int32_t *status,
+                        double det_thr, double tag_thr, float *joints, int32_t *num_people, float *ws_tags, int32_t *flags,
                         hipStream_t s)
 {
     const size_t bytes = ((size_t)K * M * (E + 3) + (size_t)M * (K + 1) * E) * 4;  // candidates + group tag lists
     const int stage = bytes <= 40 * 1024;
     hipLaunchKernelGGL(match_kernel, dim3(B), dim3(64), stage ? bytes : 0, s, tags_k, coords_k, scores_k, K, M, E, det_thr, tag_thr,
-                       joints, num_people, ws_tags, status, stage);
+                       joints, num_people, ws_tags, flags, stage);
     return hipGetLastError();
 }
 

@@ -13,9 +13,10 @@ struct hh_decoder {
     int rB = 0, rH = 0, rW = 0, rE = 0;
     float *avg = nullptr, *cellmax = nullptr, *tagb = nullptr, *cand_val = nullptr, *tags_k = nullptr, *scores_k = nullptr, *ws_tags = nullptr, *ws_prev = nullptr;
     unsigned long long *cand_key = nullptr, *ws_best = nullptr;
-    int32_t *coords_k = nullptr, *status = nullptr, *ws_jobs = nullptr;
+    int32_t *coords_k = nullptr, *flags = nullptr, *ws_jobs = nullptr;  // flags [rB]: HH_DECODE_* bits of the last call
     std::vector<void *> allocs;
     int lastB = 0, lastE = 0;
+    const int32_t *flags_last = nullptr;
     void release()
     {
         for (void *p : allocs) hipFree(p);
@@ -23,7 +24,7 @@ struct hh_decoder {
         rB = rH = rW = rE = 0;
     }
     int reserve(int B, int H, int W, int E);
-    int run(DecodeSrc &src, int adjust, int refine, float *joints, float *scores, int32_t *num_people, hipStream_t s);
+    int run(DecodeSrc &src, int adjust, int refine, float *joints, float *scores, int32_t *num_people, int32_t *flags_out, hipStream_t s);
 };
 
 static int ntiles_of(int H, int W)
@@ -54,13 +55,13 @@ int hh_decoder::reserve(int B, int H, int W, int E)
     if (alloc((size_t)nB * M * (HH_MAX_EMB + 1) * 4, (void **)&ws_prev)) return 1;
     if (alloc((size_t)nB * M * K * 8, (void **)&ws_best)) return 1;
     if (alloc(((size_t)nB * M * K * 8 + 8) * 4, (void **)&ws_jobs)) return 1;  // 8 counters + 8 job queues (one per XCD)
-    if (alloc(64, (void **)&status)) return 1;
-    HH_CHECK_HIP(hipMemset(status, 0, 64));
+    if (alloc((size_t)nB * 4, (void **)&flags)) return 1;
+    HH_CHECK_HIP(hipMemset(flags, 0, (size_t)nB * 4));
     rB = nB; rH = nH; rW = nW; rE = nE;
     return 0;
 }
 
-int hh_decoder::run(DecodeSrc &src, int adjust, int refine, float *joints, float *scores, int32_t *num_people, hipStream_t s)
+int hh_decoder::run(DecodeSrc &src, int adjust, int refine, float *joints, float *scores, int32_t *num_people, int32_t *flags_out, hipStream_t s)
 {
     src.K = K;
     src.scale_h2 = (float)(src.H / 2) / (float)src.H; src.scale_w2 = (float)(src.W / 2) / (float)src.W;
@@ -68,7 +69,8 @@ int hh_decoder::run(DecodeSrc &src, int adjust, int refine, float *joints, float
     const int nt = ntiles_of(src.H, src.W);
     HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, cellmax, s));
     HH_CHECK_HIP(launch_topk_merge(src, M, nt, cand_key, cand_val, tags_k, coords_k, scores_k, s));
-    HH_CHECK_HIP(launch_match(tags_k, coords_k, scores_k, src.B, K, M, src.E, det_thr, tag_thr, joints, num_people, ws_tags, status, s));
+    HH_CHECK_HIP(launch_match(tags_k, coords_k, scores_k, src.B, K, M, src.E, det_thr, tag_thr, joints, num_people, ws_tags, flags_out ? flags_out : flags, s));
+    flags_last = flags_out ? flags_out : flags;
     HH_CHECK_HIP(launch_adjust_scores(src, M, adjust, joints, num_people, scores, s));
     if (refine) HH_CHECK_HIP(launch_refine(src, M, joints, num_people, ws_prev, ws_best, ws_jobs, cellmax, tagb, s));
     lastB = src.B; lastE = src.E;
@@ -97,7 +99,7 @@ int hh_decoder_reserve(hh_decoder *dec, int B, int H, int W, int E) { return dec
 
 int hh_decode(hh_decoder *dec, const float *hm_q, int64_t hm_q_bstride, const float *hm_h, int64_t hm_h_bstride,
               const float *const *tags_q, const int64_t *tags_bstride, int E, int B, int hq, int wq, int adjust, int refine,
-              float *joints, float *scores, int32_t *num_people, void *stream)
+              float *joints, float *scores, int32_t *num_people, int32_t *flags, void *stream)
 {
     if (E < 1 || E > HH_MAX_EMB) { hh_set_error("hh_decode: 1 <= E <= 4"); return 1; }
     if (B <= 0 || hq <= 0 || wq <= 0 || (size_t)hq * wq * 16 >= (1u << 24)) { hh_set_error("hh_decode: bad shape (need H*W < 2^24)"); return 1; }
@@ -108,18 +110,18 @@ int hh_decode(hh_decoder *dec, const float *hm_q, int64_t hm_q_bstride, const fl
     DecodeSrc src{};
     src.mode = 0; src.avg = dec->avg; src.B = B; src.H = H; src.W = W; src.E = E;
     for (int e = 0; e < E; ++e) { src.tags_q[e] = tags_q[e]; src.tags_bs[e] = tags_bstride[e]; }
-    return dec->run(src, adjust, refine, joints, scores, num_people, s);
+    return dec->run(src, adjust, refine, joints, scores, num_people, flags, s);
 }
 
 int hh_parse(hh_decoder *dec, const float *hm_full, const float *tags_full, int E, int B, int H, int W, int adjust, int refine,
-             float *joints, float *scores, int32_t *num_people, void *stream)
+             float *joints, float *scores, int32_t *num_people, int32_t *flags, void *stream)
 {
     if (E < 1 || E > HH_MAX_EMB) { hh_set_error("hh_parse: 1 <= E <= 4"); return 1; }
     if (B <= 0 || H <= 0 || W <= 0 || (size_t)H * W >= (1u << 24)) { hh_set_error("hh_parse: bad shape (need H*W < 2^24)"); return 1; }
     if (dec->reserve(B, H, W, E)) return 1;
     DecodeSrc src{};
     src.mode = 1; src.hm_full = hm_full; src.tags_full = tags_full; src.B = B; src.H = H; src.W = W; src.E = E;
-    return dec->run(src, adjust, refine, joints, scores, num_people, (hipStream_t)stream);
+    return dec->run(src, adjust, refine, joints, scores, num_people, flags, (hipStream_t)stream);
 }
 
 int hh_resize_accumulate(const float *src, int64_t src_bstride, int B, int K, int h, int w, float *dst, int64_t dst_bstride, int H,
@@ -138,9 +140,10 @@ int hh_decoder_read_topk(hh_decoder *dec, float *tags_k, int32_t *coords_k, floa
     HH_CHECK_HIP(hipMemcpy(tags_k, dec->tags_k, n * dec->lastE * 4, hipMemcpyDeviceToHost));
     HH_CHECK_HIP(hipMemcpy(coords_k, dec->coords_k, n * 2 * 4, hipMemcpyDeviceToHost));
     HH_CHECK_HIP(hipMemcpy(scores_k, dec->scores_k, n * 4, hipMemcpyDeviceToHost));
-    int32_t st = 0;
-    HH_CHECK_HIP(hipMemcpy(&st, dec->status, 4, hipMemcpyDeviceToHost));
-    if (st) { hh_set_error("decode: assignment solver hit its iteration guard"); return 1; }
+    std::vector<int32_t> fl(dec->lastB);
+    HH_CHECK_HIP(hipMemcpy(fl.data(), dec->flags_last, fl.size() * 4, hipMemcpyDeviceToHost));
+    for (int32_t f : fl)
+        if (f & HH_DECODE_SOLVER_GUARD) { hh_set_error("decode: assignment solver hit its iteration guard"); return 1; }
     return 0;
 }
 

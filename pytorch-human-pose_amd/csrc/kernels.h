@@ -120,8 +120,9 @@ hipError_t launch_linear(const float *x, const float *w, const float *bias, floa
 hipError_t launch_preprocess(const unsigned char *img, int h, int w, const double inv[6], float *out, int H, int W,
                              const float mean[3], const float stdv[3], hipStream_t s);
 hipError_t launch_flip_images(const float *in, float *out, int B, int C, int H, int W, hipStream_t s);
+struct FlipPerm { unsigned char v[64]; };
 hipError_t launch_flip_merge(float *hm, int64_t hm_bs, const float *hmf, int64_t hmf_bs, const float *tf, int64_t tf_bs,
-                             float *to, int64_t to_bs, const int32_t *perm_dev, int B, int K, int h, int w, hipStream_t s);
+                             float *to, int64_t to_bs, const int32_t *perm_host, int B, int K, int h, int w, hipStream_t s);
 
 // Training loss (loss_kernels.hip).  scratch: >= max(HH_LOSS_SCRATCH, 2*B) doubles of device memory.
 #define HH_LOSS_SCRATCH 1024

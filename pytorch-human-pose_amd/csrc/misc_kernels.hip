@@ -79,7 +79,7 @@ hipError_t launch_flip_images(const float *in, float *out, int B, int C, int H, 
 // tags of the second pass un-flipped and permuted.  (a + b) / 2 in fp32 as torch does.
 __global__ __launch_bounds__(256) void flip_merge_kernel(float *hm, int64_t hm_bs, const float *hmf, int64_t hmf_bs,
                                                          const float *tf, int64_t tf_bs, float *to, int64_t to_bs,
-                                                         const int32_t *__restrict__ perm, int B, int K, int h, int w)
+                                                         const FlipPerm perm, int B, int K, int h, int w)
 {
     const size_t plane = (size_t)h * w, total = (size_t)B * K * plane;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void flip_merge_kernel(float *hm, int64_t hm_b
         const int y = (int)((i / w) % h);
         const int k = (int)((i / plane) % K);
         const int b = (int)(i / (plane * K));
-        const size_t src = (size_t)perm[k] * plane + (size_t)y * w + (w - 1 - x);
+        const size_t src = (size_t)perm.v[k] * plane + (size_t)y * w + (w - 1 - x);
         const size_t dst = (size_t)k * plane + (size_t)y * w + x;
         if (hm) hm[b * hm_bs + dst] = (hm[b * hm_bs + dst] + hmf[b * hmf_bs + src]) / 2.0f;
         if (to) to[b * to_bs + dst] = tf[b * tf_bs + src];
@@ -95,12 +95,14 @@ __global__ __launch_bounds__(256) void flip_merge_kernel(float *hm, int64_t hm_b
 }
 
 hipError_t launch_flip_merge(float *hm, int64_t hm_bs, const float *hmf, int64_t hmf_bs, const float *tf, int64_t tf_bs,
-                             float *to, int64_t to_bs, const int32_t *perm_dev, int B, int K, int h, int w, hipStream_t s)
+                             float *to, int64_t to_bs, const int32_t *perm_host, int B, int K, int h, int w, hipStream_t s)
 {
+    FlipPerm perm;  // K <= 64 joints: the permutation travels in the kernel arguments, no device buffer to share between streams
+    for (int k = 0; k < 64; ++k) perm.v[k] = (unsigned char)(k < K ? perm_host[k] : 0);
     const size_t total = (size_t)B * K * h * w;
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(flip_merge_kernel, dim3(grid), dim3(256), 0, s, hm, hm_bs, hmf, hmf_bs, tf, tf_bs, to, to_bs, perm_dev,
+    hipLaunchKernelGGL(flip_merge_kernel, dim3(grid), dim3(256), 0, s, hm, hm_bs, hmf, hmf_bs, tf, tf_bs, to, to_bs, perm,
                        B, K, h, w);
     return hipGetLastError();
 }

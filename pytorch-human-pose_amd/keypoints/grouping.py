@@ -49,7 +49,8 @@ class MPPEHeatmapParser:
         joints = torch.empty((B, M, K, 3 + E), device=device, dtype=torch.float32)
         scores = torch.empty((B, M), device=device, dtype=torch.float32)
         num = torch.empty((B,), device=device, dtype=torch.int32)
-        return joints, scores, num
+        flags = torch.empty((B,), device=device, dtype=torch.int32)  # HH_DECODE_* bits per image
+        return joints, scores, num, flags
 
     def parse_batch_device(self, kpts_hms: Tensor, tags_hms: Tensor, adjust: bool = True, refine: bool = True):
         """kpts_hms [B,K,H,W], tags_hms [B,K,H,W,E] (full resolution) -> device (joints, scores, num_people)."""
@@ -60,12 +61,12 @@ class MPPEHeatmapParser:
         B, K, H, W = hm.shape
         E = tg.shape[-1]
         assert K == self.num_kpts and tuple(tg.shape[:4]) == (B, K, H, W)
-        joints, scores, num = self._outputs(B, E, hm.device)
+        joints, scores, num, flags = self._outputs(B, E, hm.device)
         stream = torch.cuda.current_stream(hm.device).cuda_stream
         with torch.cuda.device(hm.device):
             _lib.check(self._lib.hh_parse(self._h, hm.data_ptr(), tg.data_ptr(), E, B, H, W, int(adjust), int(refine),
-                                          joints.data_ptr(), scores.data_ptr(), num.data_ptr(), stream))
-        return joints, scores, num
+                                          joints.data_ptr(), scores.data_ptr(), num.data_ptr(), flags.data_ptr(), stream))
+        return joints, scores, num, flags
 
     def decode_batch_device(self, hm_q: Tensor, hm_h: Tensor, tags_q: list[Tensor], adjust: bool = True, refine: bool = True):
         """Fused results.py:225-238 + parse from raw net outputs:
@@ -82,7 +83,7 @@ class MPPEHeatmapParser:
         tags_q = [view(t, hq, wq) for t in tags_q]
         if not hm_q.is_cuda:
             raise _lib.HHError("MPPEHeatmapParser needs CUDA/HIP tensors: there is no CPU path")
-        joints, scores, num = self._outputs(B, E, hm_q.device)
+        joints, scores, num, flags = self._outputs(B, E, hm_q.device)
         tptr = (C.c_void_p * E)(*[t.data_ptr() for t in tags_q])
         tbs = (C.c_int64 * E)(*[t.stride(0) for t in tags_q])
         stream = torch.cuda.current_stream(hm_q.device).cuda_stream
@@ -90,13 +91,27 @@ class MPPEHeatmapParser:
         with torch.cuda.device(hm_q.device):
             _lib.check(self._lib.hh_decode(self._h, hm_q.data_ptr(), hm_q.stride(0), hm_h.data_ptr(), hm_h.stride(0), tptr, tbs,
                                            E, B, hq, wq, int(adjust), int(refine), joints.data_ptr(), scores.data_ptr(),
-                                           num.data_ptr(), stream))
-        return joints, scores, num
+                                           num.data_ptr(), flags.data_ptr(), stream))
+        return joints, scores, num, flags
 
     @staticmethod
-    def to_lists(joints: Tensor, scores: Tensor, num: Tensor):
-        j, s, n = joints.cpu().numpy(), scores.cpu().numpy(), num.cpu().numpy()
-        return [(j[b, : n[b]].copy(), s[b, : n[b]].copy()) for b in range(j.shape[0])]
+    def to_lists(joints: Tensor, scores: Tensor, num: Tensor, flags: Tensor):
+        """Device results -> the reference's per-image `(joints [P,K,3+E], scores [P])` pairs.  Raises if the assignment solver
+        gave up on an image.  An image without any group comes back as the reference returns it (grouping.py:262-269): ONE
+        pseudo-person in float64 arrays (np.concatenate of int32 coordinates with float32 scores / tags promotes), its joint
+        scores the Python float 0.01 and the person score their float64 mean."""
+        j, s, n, f = joints.cpu().numpy(), scores.cpu().numpy(), num.cpu().numpy(), flags.cpu().numpy()
+        if (f & 2).any():
+            raise _lib.HHError(f"decode: the assignment solver hit its iteration guard on image(s) {np.nonzero(f & 2)[0].tolist()}")
+        out = []
+        for b in range(j.shape[0]):
+            jb, sb = j[b, : n[b]].copy(), s[b, : n[b]].copy()
+            if f[b] & 1:
+                jb = jb.astype(np.float64)
+                jb[..., 2] = 0.01
+                sb = jb[..., 2].mean(1)
+            out.append((jb, sb))
+        return out
 
     def last_top_k(self, B: int, E: int):
         """tags_k [B,K,M,E], coords_k [B,K,M,2], scores_k [B,K,M] of the last call (top_k, grouping.py:147-170)."""

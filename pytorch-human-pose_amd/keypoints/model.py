@@ -2,7 +2,7 @@
 
 Stands in for `/root/reference/src/keypoints/model.py:43-111` (`InferenceKeypointsModel`) and
 `/root/reference/src/base/model.py:155-175` (checkpoint loading: weights under
-ckpt["module"]["model"], prefixes `module.` / `_orig_mod.` / `net.` stripped).
+ckpt["module"]["model"] or a bare state dict, prefixes `module.` / `_orig_mod.` / `net.` stripped).
 """
 from __future__ import annotations
 
@@ -152,8 +152,12 @@ class InferenceKeypointsModel:
             self.load_checkpoint(ckpt_path)
 
     def load_checkpoint(self, ckpt_path: str) -> None:
+        """base/model.py:167-175: a trainer checkpoint keeps the weights under ["module"]["model"]; a bare state dict (the
+        published pretrained/higher_hrnet_32.pt) is loaded as it is."""
         ckpt = torch.load(ckpt_path, map_location="cpu")
-        self.net.load_state_dict(parse_checkpoint(ckpt["module"]["model"]))
+        if "module" in ckpt.keys():
+            ckpt = ckpt["module"]["model"]
+        self.net.load_state_dict(parse_checkpoint(ckpt))
 
     def prepare_input_scaled(self, image: np.ndarray, current_scale: float, min_scale: float):
         """prepare_input for one entry of a multi-scale test (get_multi_scale_size, base/transforms/utils.py:60-86)."""

@@ -118,10 +118,10 @@ def test_decode_bit_exact_vs_reference_golden(pkg, synth, decode_golden):
             if m["has_ties"]:  # torch.topk's tie order is unspecified: the oracle's index-ascending rule is the contract
                 rj, rs = orc.decode(hm_q, hm_h, tags, max_people=m["max_people"], det_thr=m["det_thr"], tag_thr=m["tag_thr"], adjust=a, refine=r)
             else:
-                rj, rs = g[tag + "/" + name].astype(np.float32), g[tag + "/scores"].astype(np.float32)
-            assert j.shape == rj.shape and np.array_equal(j, rj), (tag, name)
+                rj, rs = g[tag + "/" + name], g[tag + "/scores"]
+            assert j.dtype == rj.dtype and j.shape == rj.shape and np.array_equal(j, rj), (tag, name)
             if name == "joints":
-                assert np.array_equal(s, rs), tag
+                assert s.dtype == rs.dtype and np.array_equal(s, rs), tag
         tk, ck, sk = parser.last_top_k(1, m["emb"])
         full, tfull = orc.aggregate(hm_q, hm_h, tags)
         otk, ock, osk = orc.top_k(full, tfull, m["max_people"])
@@ -140,7 +140,7 @@ def test_parse_fullres_boundary_bit_exact(pkg, synth, decode_golden):
         full, tfull = orc.aggregate(hm_q, hm_h, tags)
         parser = pkg.MPPEHeatmapParser(17, m["max_people"], m["det_thr"], m["tag_thr"])
         j, s = parser.parse(torch.from_numpy(full).to(DEV), torch.from_numpy(tfull).to(DEV))
-        assert np.array_equal(j, g[tag + "/joints"].astype(np.float32)) and np.array_equal(s, g[tag + "/scores"].astype(np.float32)), tag
+        assert j.dtype == g[tag + "/joints"].dtype and np.array_equal(j, g[tag + "/joints"]) and s.dtype == g[tag + "/scores"].dtype and np.array_equal(s, g[tag + "/scores"]), tag
         tk, ck, sk = parser.top_k(torch.from_numpy(full).to(DEV), torch.from_numpy(tfull).to(DEV))
         pos = g[tag + "/scores_k"] > 0
         assert np.array_equal(sk[pos], g[tag + "/scores_k"][pos]) and np.array_equal(tk[pos], g[tag + "/tags_k"][pos])
@@ -425,7 +425,8 @@ def test_full_size_properties_batch32_512(pkg):
     hm_h = torch.from_numpy(np.stack([uniq[i % 4][1] for i in range(B)])).to(DEV)
     tags = torch.from_numpy(np.stack([uniq[i % 4][2][0] for i in range(B)])).to(DEV)
     parser = pkg.MPPEHeatmapParser(K, 30, 0.05, 0.5)
-    joints, scores, num = [t.clone() for t in parser.decode_batch_device(hm_q, hm_h, [tags])]
+    joints, scores, num, flags = [t.clone() for t in parser.decode_batch_device(hm_q, hm_h, [tags])]
+    assert not flags.any()
     _, _, sk = parser.last_top_k(B, 1)
     assert np.all(np.diff(sk, axis=-1) <= 0)  # per joint: candidates in descending score order
     n = num.cpu().numpy()
@@ -437,7 +438,7 @@ def test_full_size_properties_batch32_512(pkg):
         assert np.all(p[..., 0][seen] >= 0) and np.all(p[..., 0][seen] < W) and np.all(p[..., 1][seen] >= 0) and np.all(p[..., 1][seen] < H)
         assert np.array_equal(j[b], j[b % 4]) and n[b] == n[b % 4]  # the batch repeats 4 distinct images
     for b in (0, 5):
-        j1, s1, n1 = parser.decode_batch_device(hm_q[b:b + 1], hm_h[b:b + 1], [tags[b:b + 1]])
+        j1, s1, n1, _ = parser.decode_batch_device(hm_q[b:b + 1], hm_h[b:b + 1], [tags[b:b + 1]])
         assert int(n1[0]) == int(n[b]) and torch.equal(j1[0], joints[b]) and torch.equal(s1[0], scores[b])
     # the oracle agrees on one of the full-size images (takes ~0.3 s per image)
     rj, rs = orc.decode(uniq[0][0], uniq[0][1], [uniq[0][2][0]], max_people=30, det_thr=0.05, tag_thr=0.5)

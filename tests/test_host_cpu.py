@@ -17,7 +17,7 @@ def test_capi_exports_every_declared_symbol(pkg):
     assert len(names) >= 27
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.hh_abi_version() == 1
+    assert lib.hh_abi_version() == 2
 
 
 @pytest.mark.parametrize("C", [32, 48])
@@ -94,6 +94,23 @@ def test_parse_checkpoint_prefixes(pkg):
     mod = importlib.import_module(PKG + ".keypoints.model")
     out = mod.parse_checkpoint({"module.net.backbone.conv1.weight": 1, "_orig_mod.net.init_heatmaps_head.bias": 2})
     assert out == {"backbone.conv1.weight": 1, "init_heatmaps_head.bias": 2}
+
+
+def test_load_checkpoint_accepts_trainer_and_bare_layouts(tmp_path):
+    """base/model.py:167-175: weights under ["module"]["model"] (trainer checkpoint) or a bare state dict (the published
+    pretrained file); DDP / torch.compile / wrapper prefixes stripped either way."""
+    import types
+    import torch
+    from torch import nn
+    mod = importlib.import_module(PKG + ".keypoints.model")
+    src = nn.Conv2d(3, 4, 3)
+    sd = {"module.net." + k: v.clone() for k, v in src.state_dict().items()}
+    for name, payload in (("trainer.pt", {"module": {"model": sd, "optimizers": {}}, "epoch": 3}), ("bare.pt", sd)):
+        path = str(tmp_path / name)
+        torch.save(payload, path)
+        dst = nn.Conv2d(3, 4, 3)
+        mod.InferenceKeypointsModel.load_checkpoint(types.SimpleNamespace(net=dst), path)
+        assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values())), name
 
 
 def test_coco_result_packing_matches_reference_layout():
