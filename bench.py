@@ -9,13 +9,18 @@ One "step" = one pass of the hot path over one batch of synthetic input resident
 Multi-GPU: the path shards by image (no collective on the data path); every rank runs the same
 per-GPU batch (weak scaling), timing is barrier + synchronize on both sides, max over ranks.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live inside the timed region: steps 1..K-1 run as they would in
-production (eager launches, branch lanes on internal streams, decode on a second stream); in the K-th (last) timed step
-the kernels run one at a time on one stream and every convolution launch is timed twice -- by the kernel itself on the
-device wall clock (first workgroup start to last workgroup end: the figure rocprofv3's kernel trace reports) and by a
-HIP-event bracket on the launch stream (hh_profile_*).  The dominant kernel instantiation is the one with the largest
-summed time in that step.  `decode_roofline` = compulsory decode bytes over the time of hh_decode alone, against HBM
-peak.  `cpu_baseline` times the CPU oracle (oracle/) on a bounded sample, on rank 0 at N=1 only.
+The two halves are issued back to back on ONE stream, so a step costs forward + decode ("reported
+separately and summed"); `--overlap` puts the decode on a second stream beside the forward (serving: decode of batch i
+runs beside the forward of batch i+1), which is a few percent faster and is NOT the headline.
+
+Prints ONE JSON line (rank 0).  The K timed steps run as in production (eager launches, branch lanes on internal
+streams).  `roofline` comes from probe steps AFTER the timed loop (not part of `value`): the kernels run one at a time on
+one stream and every convolution launch carries a start / stop HIP event pair that the runtime fills from the dispatch
+packet's own begin / end timestamps (hipExtLaunchKernelGGL, on the stream the kernel is launched on) -- the clock pair
+rocprofv3's kernel trace reports, so `avg_launch_us` is directly comparable with the serial pass committed in
+profiles/rNN_bench_kernel_stats.csv.  The dominant kernel instantiation is the one with the largest summed time.
+`decode_roofline` = compulsory decode bytes over the time of hh_decode alone, against HBM peak.  `cpu_baseline` times
+the CPU oracle (oracle/) on a bounded sample, on rank 0 at N=1 only.
 """
 import argparse
 import ctypes as C
@@ -96,6 +101,53 @@ def cpu_baseline(pkg, sd, maps, fwd_images=4, dec_images=8):
     }
 
 
+def timed_loop(step, warmup, steps, dist, sync, reduce_device):
+    """The driver's timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + device
+    synchronize on both sides; returns the MAX over ranks of the elapsed seconds.  Shared by the inference bench, the
+    training bench and the CPU rehearsal of the N > 1 launch contract (tests/test_distributed_cpu.py)."""
+    last = None
+    for _ in range(warmup):
+        last = step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=reduce_device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, last
+
+
+def headline(metric, world, per_gpu_batch, args, elapsed, dtype, config):
+    """The one JSON line of the contract; `value` is the whole-job aggregate over all ranks."""
+    return {
+        "metric": metric, "value": round(world * per_gpu_batch * args.steps / elapsed, 2), "unit": "images/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic", "config": config,
+    }
+
+
+def rehearsal_cpu(args, dist, rank, world):
+    """HH_BENCH_REHEARSAL=cpu: the N > 1 launch contract without a GPU (gloo): same process-group init, same timed_loop,
+    same rank-0 line; a step is a sleep whose length depends on the rank, so the test can see that the MAX was taken."""
+    elapsed, _ = timed_loop(lambda: time.sleep(0.002 * (rank + 1)), args.warmup, args.steps, dist, lambda: None, "cpu")
+    if rank == 0:
+        print(json.dumps(headline("images/sec (fwd+decode) HigherHRNet-W32 512px", world, args.batch, args, elapsed, "bf16",
+                                  {"workload": "CPU rehearsal of the multi-rank launch contract (no GPU work)", "global_batch": world * args.batch,
+                                   "parallelism": f"image-sharded replicas x{world}, no data-path collective"})), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def train_bench(args, pkg, dist, rank, world, dev):
     """Training step of configs[2] (keypoints/module.py:43-71): per-GPU batch `--batch` (32 x 8 GPUs = the global batch 256),
     synthetic images and targets, bf16 activations.  One step = forward (batch-statistics BN) + AEKeypointsLoss + backward +
@@ -131,35 +183,16 @@ def train_bench(args, pkg, dist, rank, world, dev):
     train_stream = torch.cuda.Stream(dev, priority=prio)
     train_stream.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(train_stream):
-        for _ in range(max(args.warmup, 1)):
-            loss = step()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        args.warmup = max(args.warmup, 1)
+        elapsed, loss = timed_loop(step, args.warmup, args.steps, dist, torch.cuda.synchronize, dev)
     if rank == 0:
-        print(json.dumps({
-            "metric": "images/sec (training step) HigherHRNet-W32 512px", "value": round(world * B * args.steps / elapsed, 2),
-            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"HigherHRNet-W32 training step, batch {B} @ 512x512 per GPU: forward (train-mode BN) + AE loss + "
-                                   f"backward + Adam, {args.people} people/image", "global_batch": world * B,
-                       "parallelism": f"DistributedDataParallel x{world} (gradient all-reduce on RCCL, BatchNorm per rank as in the reference's experiment file)" if world > 1 else "single GPU",
-                       "final_loss": round(float(loss.item()), 5),
-                       "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)},
-        }), flush=True)
+        print(json.dumps(headline(
+            "images/sec (training step) HigherHRNet-W32 512px", world, B, args, elapsed, "bf16",
+            {"workload": f"HigherHRNet-W32 training step, batch {B} @ 512x512 per GPU: forward (train-mode BN) + AE loss + "
+                         f"backward + Adam, {args.people} people/image", "global_batch": world * B,
+             "parallelism": f"DistributedDataParallel x{world} (gradient all-reduce on RCCL, BatchNorm per rank as in the reference's experiment file)" if world > 1 else "single GPU",
+             "final_loss": round(float(loss.item()), 5),
+             "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)})), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -168,13 +201,16 @@ def train_bench(args, pkg, dist, rank, world, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--people", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="no per-launch HIP events in the last timed step")
-    ap.add_argument("--sequential", action="store_true", help="issue decode behind the forward on one stream")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch probe steps behind the timed loop")
+    ap.add_argument("--probe-steps", type=int, default=3, help="serial probe steps behind the timed loop (roofline line)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="issue the decode on a second stream beside the forward instead of behind it (not the headline)")
+    ap.add_argument("--sequential", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--single-lane", action="store_true",
                     help="no internal branch streams: kernels run one after another (what the roofline probe and the "
                          "isolated-kernel rocprofv3 pass measure)")
@@ -190,6 +226,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("HH_BENCH_REHEARSAL") == "cpu":
+            dist.init_process_group(backend="gloo")
+            return rehearsal_cpu(args, dist, rank, world)
         if os.environ.get("HH_BENCH_REHEARSAL"):
             # rehearsal of the N > 1 code path on a ONE-GPU box (every rank on cuda:0, gloo): checks the launch contract
             # (barriers, max over ranks, rank-0 line), not performance - the driver's multi-GPU runs use RCCL below
@@ -227,45 +266,31 @@ def main():
     outs = (torch.empty(B, 2 * K, H // 4, W // 4, device=dev), torch.empty(B, K, H // 2, W // 2, device=dev))
 
     def step(isolate=False):
-        # The two halves of a step have no data dependency (forward consumes images, decode consumes maps -- in
-        # serving, decode of batch i runs beside the forward of batch i+1), so they are issued on two streams
-        # unless --sequential is given.
+        # forward, then decode behind it on the same stream: a step costs their sum.  --overlap: the two
+        # halves have no data dependency (the decode consumes constructed maps), so the decode may run on a second stream.
         out = net.forward_raw(images, outs)
-        if args.sequential or isolate:
-            dec = parser.decode_batch_device(hm_q, hm_h, [tags], adjust=True, refine=True)
-        else:
+        if args.overlap and not isolate:
             with torch.cuda.stream(side2):
                 dec = parser.decode_batch_device(hm_q, hm_h, [tags], adjust=True, refine=True)
+        else:
+            dec = parser.decode_batch_device(hm_q, hm_h, [tags], adjust=True, refine=True)
         return out, dec
 
     stream = torch.cuda.current_stream(dev)
     with torch.cuda.stream(side):
         profile = not args.no_profile
         net.use_graph = True
-        for _ in range(args.warmup):
-            step()
-        side.synchronize()
-        side2.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            if profile and i == args.steps - 1:
-                # last timed step: conv launches one at a time with the device-clock probe + HIP events, and the decode
-                # behind them on the same stream (a decode kernel running beside a probed conv would inflate its duration)
-                side2.synchronize()
-                lib.hh_profile_enable(net._h, 1)
-                out, dec = step(isolate=True)
-                continue
-            out, dec = step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        per_cfg = collect_profile(pkg, net) if profile else {}
-        lib.hh_profile_enable(net._h, 0)
+        elapsed, (out, dec) = timed_loop(step, args.warmup, args.steps, dist, torch.cuda.synchronize, dev)
+        per_cfg = {}
+        if profile:
+            # probe steps, outside the timed region: conv launches one at a time on one stream, each with its own start / stop
+            # event pair (hipExtLaunchKernelGGL), the decode behind them on the same stream
+            lib.hh_profile_enable(net._h, 1)
+            for _ in range(max(1, args.probe_steps)):
+                step(isolate=True)
+            side.synchronize()
+            per_cfg = collect_profile(pkg, net)
+            lib.hh_profile_enable(net._h, 0)
         # split of the step (not part of the timed region): forward alone / decode alone, graph replay
         net.use_graph = True
         for fn in (lambda: net.forward_raw(images, outs), lambda: parser.decode_batch_device(hm_q, hm_h, [tags])):
@@ -279,29 +304,11 @@ def main():
             side.synchronize()
             parts.append((time.perf_counter() - t1) / 5)
     del stream
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     num_people = int(dec[2].sum().item())
+    assert not bool(dec[3].any().item()), "decode flagged an image (solver guard / no-group fallback) on the bench maps"
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
-        line = {
-            "metric": "images/sec (fwd+decode) HigherHRNet-W32 512px",
-            "value": round(value, 2),
-            "unit": "images/sec",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16",
-            "data": "synthetic",
-            "config": {
+        line = headline("images/sec (fwd+decode) HigherHRNet-W32 512px", world, B, args, elapsed, "bf16", {
                 "workload": f"HigherHRNet-W32 inference bf16, batch {B} @ 512x512 per GPU (conv fwd on N(0,1) images + AE decode "
                             f"on constructed maps, {args.people} people/image, det_thr 0.05, tag_thr 0.5, adjust+refine)",
                 "global_batch": world * B,
@@ -310,12 +317,10 @@ def main():
                 "forward_ms": round(parts[0] * 1e3, 3),
                 "decode_ms": round(parts[1] * 1e3, 3),
                 "forward_tflops": round(net.forward_flops(B, H, W) / parts[0] / 1e12, 1),
-                "streams": "forward and decode issued back to back on one stream" if args.sequential else
-                           "forward (+3 internal branch lanes) and decode on two streams",
-                "timed_region": "eager multi-lane launches, decode on a second stream; last step: kernels one at a time on one stream with the per-launch probe" if profile
-                                else "eager multi-lane launches",
-            },
-        }
+                "streams": "forward (+3 internal branch lanes) and decode on two streams" if args.overlap else
+                           "forward (+3 internal branch lanes), then decode, back to back on one stream: step = forward + decode",
+                "timed_region": "eager launches as in production; the per-launch roofline probe runs in separate steps behind the timed loop",
+        })
         if per_cfg:
             dom = max(per_cfg, key=lambda c: per_cfg[c]["ms"])
             d = per_cfg[dom]
@@ -325,12 +330,12 @@ def main():
                      101: "junction_kernel (stage-0 conv3 1x1 [+downsample] + residual + ReLU + next conv1 1x1 + ReLU)"}.get(dom, str(dom))
             if lib.hh_conv_config(dom, cfgv) == 0:
                 kname = "conv_mfma_kernel<KS=%d,S=%d,KC=%d,NT=%d,WC=%d,PT=%d,TW=%d>" % tuple(cfgv)
-            # Per-launch duration = first-workgroup-start .. last-workgroup-end read by the kernel itself from the device
-            # wall clock during the last timed step; it is the quantity rocprofv3's kernel trace reports (serial pass in
-            # profiles/rNN_summary.md).  The HIP-event bracket recorded around the same launches on the launch stream is
-            # reported beside it: it adds the two marker packets and the dispatch gap (~4-7 us) to every ~18 us launch.
-            achieved = d["flops"] / (d["kms"] * 1e-3) / 1e12
-            total_ms = sum(v["kms"] for v in per_cfg.values())
+            # Per-launch duration = the dispatch packet's begin .. end timestamps, delivered through the start / stop events of
+            # hipExtLaunchKernelGGL on the launch stream: the quantity rocprofv3's kernel trace reports (serial pass in
+            # profiles/rNN_bench_kernel_stats.csv).  The kernel's own first-workgroup-start .. last-workgroup-end on the device
+            # wall clock is reported beside it (shorter: no dispatch ramp, no end-of-kernel write-back).
+            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            total_ms = sum(v["ms"] for v in per_cfg.values())
             line["roofline"] = {
                 "bound": "mfma",
                 "achieved": round(achieved, 2),
@@ -340,20 +345,20 @@ def main():
                 "traffic": traffic_for(kname),
                 "kernel": kname,
                 "launches": d["n"],
-                "avg_launch_us": round(d["kms"] / d["n"] * 1e3, 2),
-                "avg_launch_us_hip_events": round(d["ms"] / d["n"] * 1e3, 2),
-                "achieved_hip_events": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),
-                "timing": "device wall clock inside the kernel (first workgroup start to last workgroup end), last timed step, "
-                          "kernels serialised on one stream; HIP-event bracket of the same launches alongside",
+                "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 2),
+                "avg_launch_us_device_clock": round(d["kms"] / d["n"] * 1e3, 2),
+                "achieved_device_clock": round(d["flops"] / (d["kms"] * 1e-3) / 1e12, 2),
+                "timing": "HIP start/stop events of each launch (hipExtLaunchKernelGGL: dispatch begin/end timestamps, what rocprofv3's "
+                          "kernel trace reports), probe steps behind the timed loop, kernels serialised on one stream",
                 "avg_launch_gflop": round(d["flops"] / d["n"] / 1e9, 3),
                 # the same launches against the HBM side of the roofline: algorithmic bytes (input + output + residual +
                 # weights, once each) over the same durations, and the two-sided ceiling min(MFMA peak, AI x HBM peak)
                 "avg_launch_mbytes": round(d["bytes"] / d["n"] / 1e6, 2),
-                "achieved_hbm_gbs": round(d["bytes"] / (d["kms"] * 1e-3) / 1e9, 1),
-                "hbm_frac": round(d["bytes"] / (d["kms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "achieved_hbm_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
+                "hbm_frac": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "roofline_ceiling_tflops": round(d["flops"] / d["ceil_s"] / 1e12, 1),
-                "frac_of_ceiling": round(d["ceil_s"] / (d["kms"] * 1e-3), 4),
-                "share_of_conv_time": round(d["kms"] / total_ms, 3),
+                "frac_of_ceiling": round(d["ceil_s"] / (d["ms"] * 1e-3), 4),
+                "share_of_conv_time": round(d["ms"] / total_ms, 3),
                 "all_conv_tflops": round(sum(v["flops"] for v in per_cfg.values()) / (total_ms * 1e-3) / 1e12, 2),
             }
         # decode half against the HBM roofline: compulsory bytes (read every network output once) over the

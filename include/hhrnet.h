@@ -83,10 +83,11 @@ double hh_forward_flops(const hh_net *net, int B, int H, int W);
  * launch since hh_profile_enable: kernel instantiation index, algorithmic FLOPs (2*MACs) and bytes (input + output
  * (+ residual) + weights, each once: no halo re-reads) of that launch,
  * elapsed milliseconds, and the state-dict prefix of the layer.  hh_conv_config describes an
- * instantiation as {KS, S, KC, NT, WC, PT, TW}.  `ms` is the HIP-event bracket (it includes the two
- * marker packets and the dispatch gap, ~4 us); `kernel_ms` is first-workgroup-start to last-workgroup-end
- * read by the kernel itself from the device wall clock (hipDeviceAttributeWallClockRate), the figure that
- * rocprofv3's kernel trace reports; -1 when unavailable.                                                */
+ * instantiation as {KS, S, KC, NT, WC, PT, TW}.  `ms` = hipEventElapsedTime of the start / stop events the launch itself
+ * was given (hipExtLaunchKernelGGL): the runtime fills them from the dispatch packet's begin / end timestamps, the same
+ * clock pair rocprofv3's kernel trace reports.  `kernel_ms` is first-workgroup-start to last-workgroup-end read by the
+ * kernel itself from the device wall clock (hipDeviceAttributeWallClockRate): shorter, it leaves out the dispatch ramp
+ * and the end-of-kernel write-back; -1 when unavailable.                                                            */
 int hh_profile_enable(hh_net *net, int enable);
 int hh_profile_count(const hh_net *net);
 int hh_profile_get(hh_net *net, int index, int *cfg, double *flops, double *bytes, float *ms, float *kernel_ms, const char **layer);

@@ -377,6 +377,6 @@ hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s)
     if (hipGetDevice(&dev) != hipSuccess || !g_trash_dev[dev & 63]) return hipErrorNotInitialized;
     p.trash = g_trash_dev[dev & 63];
     const int grid = p.ntiles < num_cus ? p.ntiles : num_cus;
-    hipLaunchKernelGGL(bb_fused_kernel, dim3(grid), dim3(NTHR), bb_fused_lds_bytes(), s, p);
+    HH_LAUNCH(bb_fused_kernel, dim3(grid), dim3(NTHR), bb_fused_lds_bytes(), s, p);
     return hipGetLastError();
 }

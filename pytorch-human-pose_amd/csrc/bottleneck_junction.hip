@@ -192,7 +192,7 @@ hipError_t junction_launch(const JuncParams &p, int num_cus, hipStream_t s)
     const int ngroups = (p.npix + 127) / 128;
     const int per_cu = ds ? 1 : 2;  // 96 KB + vs 64 KB + of LDS
     const int grid = ngroups < num_cus * per_cu ? ngroups : num_cus * per_cu;
-    if (ds) hipLaunchKernelGGL(junction_kernel<true>, dim3(grid), dim3(256), junc_lds(true), s, p);
-    else hipLaunchKernelGGL(junction_kernel<false>, dim3(grid), dim3(256), junc_lds(false), s, p);
+    if (ds) HH_LAUNCH(junction_kernel<true>, dim3(grid), dim3(256), junc_lds(true), s, p);
+    else HH_LAUNCH(junction_kernel<false>, dim3(grid), dim3(256), junc_lds(false), s, p);
     return hipGetLastError();
 }

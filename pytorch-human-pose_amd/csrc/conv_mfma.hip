@@ -419,6 +419,6 @@ hipError_t conv_launch(int cfg_index, const ConvParams &p, hipStream_t stream)
     const ConvConfig &c = g_configs[cfg_index];
     const unsigned tiles = (unsigned)p.B * p.tiles_y * p.tiles_x, sf = (unsigned)p.ncg * (p.nphase > 1 ? p.nphase : 1);
     const unsigned grid = sf > 1 ? (tiles + 7) / 8 * 8 * sf : tiles;  // groups of 8 tiles x sf variants (see the kernel)
-    hipLaunchKernelGGL(g_fns[cfg_index], dim3(grid), dim3(256), c.lds_bytes(), stream, p);
+    HH_LAUNCH(g_fns[cfg_index], dim3(grid), dim3(256), c.lds_bytes(), stream, p);
     return hipGetLastError();
 }

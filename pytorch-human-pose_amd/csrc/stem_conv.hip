@@ -134,6 +134,6 @@ hipError_t stem_conv_launch(const StemParams &p, hipStream_t s)
 {
     const int Ho = p.H >> 1, Wo = p.W >> 1;
     const int grid = p.B * ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW);
-    hipLaunchKernelGGL(stem_conv_kernel, dim3(grid), dim3(256), 0, s, p);
+    HH_LAUNCH(stem_conv_kernel, dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }

@@ -87,3 +87,29 @@ def test_shard_range_partitions():
             parts = [list(d.shard_range(n, r, w)) for r in range(w)]
             assert sum(parts, []) == list(range(n))
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_bench_multi_rank_launch_contract_two_ranks():
+    """bench.py under the driver's N > 1 command line (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`),
+    rehearsed on CPU over gloo (HH_BENCH_REHEARSAL=cpu swaps the GPU step for a rank-dependent sleep; process-group init,
+    the barrier/synchronize bracket, the MAX over ranks and the rank-0 line are the code the real multi-GPU run executes)."""
+    import json
+    import subprocess
+    port = 29500 + (os.getpid() + 191) % 2000
+    env = dict(os.environ, HH_BENCH_REHEARSAL="cpu", OMP_NUM_THREADS="1")
+    steps, warmup, batch = 5, 1, 32
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # exactly one line, from rank 0
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in r, key
+    assert r["n_gpus"] == 2 and r["steps"] == steps and r["warmup"] == warmup and r["scaling"] == "weak" and r["higher_is_better"] is True
+    assert r["config"]["global_batch"] == 2 * batch and r["vs_baseline"] is None
+    # rank 1 sleeps 4 ms per step, rank 0 2 ms: the reported time is the slower rank's (MAX over ranks) ...
+    assert r["ms_per_step"] >= 4.0
+    # ... and the value is the whole-job aggregate over both ranks for that time
+    assert abs(r["value"] - 2 * batch / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-3
