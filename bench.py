@@ -290,6 +290,14 @@ def main():
                 step(isolate=True)
             side.synchronize()
             per_cfg = collect_profile(pkg, net)
+            # one more step with the in-kernel device-clock stamps (a side figure; its atomics lengthen the launches, so it
+            # is never mixed with the event timing above)
+            lib.hh_profile_enable(net._h, 2)
+            step(isolate=True)
+            side.synchronize()
+            for c, d in collect_profile(pkg, net).items():
+                if c in per_cfg:
+                    per_cfg[c]["kms"] = d["kms"] * per_cfg[c]["n"] / d["n"]
             lib.hh_profile_enable(net._h, 0)
         # split of the step (not part of the timed region): forward alone / decode alone, graph replay
         net.use_graph = True

@@ -87,7 +87,8 @@ double hh_forward_flops(const hh_net *net, int B, int H, int W);
  * was given (hipExtLaunchKernelGGL): the runtime fills them from the dispatch packet's begin / end timestamps, the same
  * clock pair rocprofv3's kernel trace reports.  `kernel_ms` is first-workgroup-start to last-workgroup-end read by the
  * kernel itself from the device wall clock (hipDeviceAttributeWallClockRate): shorter, it leaves out the dispatch ramp
- * and the end-of-kernel write-back; -1 when unavailable.                                                            */
+ * and the end-of-kernel write-back; only with hh_profile_enable(net, 2) -- the same-address atomics that stamp it lengthen
+ * each launch by 3-5 us as the dispatch timestamps see it, so mode 1 (events only) is the one to quote -- else -1.     */
 int hh_profile_enable(hh_net *net, int enable);
 int hh_profile_count(const hh_net *net);
 int hh_profile_get(hh_net *net, int index, int *cfg, double *flops, double *bytes, float *ms, float *kernel_ms, const char **layer);

@@ -108,7 +108,7 @@ int hh_debug_check_plan(const hh_net *net)
     return 0;
 }
 
-int hh_profile_enable(hh_net *net, int enable) { net->prof_enabled = enable != 0; net->prof_used = 0; return 0; }
+int hh_profile_enable(hh_net *net, int enable) { net->prof_enabled = enable != 0; net->prof_clk = enable == 2; net->prof_used = 0; return 0; }
 int hh_profile_count(const hh_net *net) { return (int)net->prof_used; }
 int hh_profile_get(hh_net *net, int i, int *cfg, double *flops, double *bytes, float *ms, float *kernel_ms, const char **layer)
 {
@@ -119,7 +119,7 @@ int hh_profile_get(hh_net *net, int i, int *cfg, double *flops, double *bytes, f
     *cfg = r.cfg; *flops = r.flops; *bytes = r.bytes;
     *layer = net->layers[net->ops[r.op].layer].conv.c_str();
     *kernel_ms = -1.f;
-    if (r.slot >= 0 && net->d_clk && net->clk_khz > 0) {
+    if (r.slot >= 0 && net->prof_clk && net->d_clk && net->clk_khz > 0) {
         unsigned long long t[2];
         HH_CHECK_HIP(hipMemcpy(t, net->d_clk + 2 * r.slot, 16, hipMemcpyDeviceToHost));
         if (t[1] > t[0]) *kernel_ms = (float)((double)(t[1] - t[0]) / net->clk_khz);

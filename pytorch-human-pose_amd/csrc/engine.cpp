@@ -701,7 +701,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->flops = 2.0 * B * (H / 2) * (W / 2) * 27.0 * 64.0;
                 pr->bytes = (double)B * H * W * 3 * 4 + (double)B * (H / 2) * (W / 2) * 64 * 2 + 64 * 32 * 2;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
-                if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
+                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 2 * pr->slot;
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
             }
             HH_CHECK_HIP(stem_conv_launch(p, s));
@@ -767,7 +767,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->bytes = 2.0 * p.npix * (64 + (op.in2 >= 0 ? 64 : 256) + 256 + (op.layer3 >= 0 ? 64 : 0)) +
                             2.0 * 64 * 256 * (1 + (op.in2 >= 0) + (op.layer3 >= 0));
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
-                if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
+                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 2 * pr->slot;
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
             }
             HH_CHECK_HIP(junction_launch(p, num_cus, s));
@@ -792,7 +792,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->op = (int)(&op - ops.data());
                 pr->cfg = HH_CFG_BB_FUSED;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
-                if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
+                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 2 * pr->slot;
                 pr->flops = 2.0 * 2.0 * B * p.H * p.W * 32.0 * 32.0 * 9.0;
                 pr->bytes = 2.0 * B * p.H * p.W * 32 * 2 + 2.0 * 2 * 9 * 32 * 32;
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
@@ -848,7 +848,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->op = (int)(&op - ops.data());
                 pr->cfg = cfg;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
-                if (pr->slot >= 0) p.clk = d_clk + 2 * pr->slot;
+                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 2 * pr->slot;
                 pr->flops = 2.0 * B * p.Ho * p.Wo * (double)l.cin * l.cout * l.ks * l.ks * (p.nphase > 1 ? 4 : 1);
                 {
                     const double opix = (double)B * p.Ho * p.Wo * (p.nphase > 1 ? 4 : 1);

@@ -111,6 +111,7 @@ struct hh_net {
     std::vector<GraphEntry> graphs;
     // live per-launch timing (bench.py roofline): HIP events on the launch stream around every conv
     bool prof_enabled = false;
+    bool prof_clk = false;  // also stamp the device clock inside the kernels (their same-address atomics lengthen the launch by ~3-5 us)
     std::vector<ProfRecord> prof;
     size_t prof_used = 0;
     unsigned long long *d_clk = nullptr;  // [HH_PROF_SLOTS][2]

@@ -196,7 +196,7 @@ def _decode_both(pkg, hm_q, hm_h, tags, K, maxp=30, det=0.05, tthr=0.5):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None].to(DEV)  # noqa: E731
     j, s = parser.to_lists(*parser.decode_batch_device(t(hm_q), t(hm_h), [t(x) for x in tags]))[0]
     rj, rs = orc.decode(hm_q, hm_h, tags, max_people=maxp, det_thr=det, tag_thr=tthr)
-    assert j.shape == rj.shape and np.array_equal(j, rj) and np.array_equal(s, rs)
+    assert j.dtype == rj.dtype and j.shape == rj.shape and np.array_equal(j, rj) and s.dtype == rs.dtype and np.array_equal(s, rs)
     return j, s
 
 
@@ -208,7 +208,7 @@ def test_decode_degenerate_and_edge_inputs(pkg, synth):
     z = lambda *s: np.zeros(s, np.float32)  # noqa: E731
     # all zeros -> no candidate above det_thr -> fallback person (grouping.py:262-269)
     j, s = _decode_both(pkg, z(K, hq, wq), z(K, 2 * hq, 2 * wq), [z(K, hq, wq)], K)
-    assert j.shape[0] == 1 and np.all(j[0, :, 2] == np.float32(0.01))
+    assert j.shape[0] == 1 and j.dtype == np.float64 and s.dtype == np.float64 and np.all(j[0, :, 2] == 0.01)  # float64, as the reference returns it
     # constant positive maps: every pixel is a tied local maximum above det_thr
     c = np.full((K, hq, wq), 0.5, np.float32)
     _decode_both(pkg, c, np.full((K, 2 * hq, 2 * wq), 0.5, np.float32), [z(K, hq, wq)], K)
