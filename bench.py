@@ -38,9 +38,17 @@ sys.path.insert(0, REPO)
 PKG = "pytorch-human-pose_amd"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+MFMA_FP8_DENSE_PEAK_TFLOPS = 5000.0   # same table: "Peak FP8 MFMA ~5 PF dense"
+# BASELINE.json configs a bench line can be quoted on: [1] (the headline, default) and [4] (the fp8 conv path)
+CONFIGS = {
+    "w32_b32_512": dict(C=32, dtype="bf16", batch=32, size=512, peak=MFMA_BF16_DENSE_PEAK_TFLOPS,
+                        metric="images/sec (fwd+decode) HigherHRNet-W32 512px", name="HigherHRNet-W32 inference bf16"),
+    "fp8_w48_b64_640": dict(C=48, dtype="fp8", batch=64, size=640, peak=MFMA_FP8_DENSE_PEAK_TFLOPS,
+                            metric="images/sec (fwd+decode) HigherHRNet-W48 fp8 640px", name="HigherHRNet-W48 inference fp8 (e4m3 MFMA conv path)"),
+}
 
 
-def collect_profile(pkg, net):
+def collect_profile(pkg, net, peak=MFMA_BF16_DENSE_PEAK_TFLOPS):
     lib = pkg._lib.load()
     n = lib.hh_profile_count(net._h)
     """-> {cfg: {n, ms, kms, flops}}: per-launch times summed per kernel instantiation.  ms = HIP-event bracket on the
@@ -57,7 +65,7 @@ def collect_profile(pkg, net):
         d["flops"] += flops.value
         d["bytes"] += nbytes.value
         # roofline time of this launch: max(FLOPs / MFMA peak, algorithmic bytes / HBM peak)
-        d["ceil_s"] += max(flops.value / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), nbytes.value / (HBM_PEAK_GBS * 1e9))
+        d["ceil_s"] += max(flops.value / (peak * 1e12), nbytes.value / (HBM_PEAK_GBS * 1e9))
     return per_cfg
 
 
@@ -72,14 +80,14 @@ def traffic_for(kernel_name):
         return json.load(f)["bytes_per_launch"].get(kernel_name)
 
 
-def cpu_baseline(pkg, sd, maps, fwd_images=4, dec_images=8):
+def cpu_baseline(pkg, sd, maps, fwd_images=4, dec_images=8, size=512):
     """The oracle (a port of the reference's path, kind="port") timed on this host."""
     from oracle import decode as orc
     from oracle import forward as ofw
 
     nthreads = min(32, os.cpu_count() or 1)  # torch's CPU convs stop scaling (and regress) far below 128 threads
     torch.set_num_threads(nthreads)
-    x = torch.from_numpy(pkg.synth.synth_images(fwd_images, 512, 512, 0))
+    x = torch.from_numpy(pkg.synth.synth_images(fwd_images, size, size, 0))
     with torch.no_grad():
         ofw.higher_hrnet(x[:1], sd, 17)  # warm-up
         t0 = time.perf_counter()
@@ -96,7 +104,7 @@ def cpu_baseline(pkg, sd, maps, fwd_images=4, dec_images=8):
         "unit": "images/sec",
         "cores": nthreads,
         "kind": "port",
-        "sample": f"oracle fp32 forward on {fwd_images} images 512x512 ({nthreads} threads, {t_fwd * 1e3:.0f} ms/img) + "
+        "sample": f"oracle fp32 forward on {fwd_images} images {size}x{size} ({nthreads} threads, {t_fwd * 1e3:.0f} ms/img) + "
                   f"C oracle decode on {dec_images} images (1 thread, {t_dec * 1e3:.0f} ms/img), host has {os.cpu_count()} cpus",
     }
 
@@ -203,7 +211,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default: the config's)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="w32_b32_512",
+                    help="BASELINE.json workload: w32_b32_512 = configs[1] (headline), fp8_w48_b64_640 = configs[4]")
     ap.add_argument("--people", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch probe steps behind the timed loop")
@@ -219,6 +229,9 @@ def main():
                          "backward + Adam, DistributedDataParallel over RCCL when launched on several GPUs); not the headline metric")
     args = ap.parse_args()
 
+    cfgd = CONFIGS[args.config]
+    if args.batch is None:
+        args.batch = cfgd["batch"]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -240,14 +253,16 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     pkg = importlib.import_module(PKG)
 
-    B, H, W, K = args.batch, 512, 512, 17
+    B, H, W, K = args.batch, cfgd["size"], cfgd["size"], 17
     if args.train:
         return train_bench(args, pkg, dist, rank, world, dev)
-    net = pkg.HigherHRNet(K, 32)
+    net = pkg.HigherHRNet(K, cfgd["C"], dtype=cfgd["dtype"])
     sd = {k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()}
     net.load_state_dict(sd)
     net.to(dev).eval()
     images = torch.from_numpy(pkg.synth.synth_images(B, H, W, seed=rank)).to(dev)
+    if cfgd["dtype"] == "fp8":  # activation scales from a calibration batch of the same distribution (other seed)
+        net.calibrate(torch.from_numpy(pkg.synth.synth_images(8, H, W, seed=4242)).to(dev))
     uniq = [pkg.synth.synth_decode_maps(K, H // 4, W // 4, args.people, seed=1000 + rank * 8 + i)[:3] for i in range(8)]
     uniq = [(a, b, t[0]) for a, b, t in uniq]
     hm_q = torch.from_numpy(np.stack([uniq[i % 8][0] for i in range(B)])).to(dev)
@@ -289,13 +304,13 @@ def main():
             for _ in range(max(1, args.probe_steps)):
                 step(isolate=True)
             side.synchronize()
-            per_cfg = collect_profile(pkg, net)
+            per_cfg = collect_profile(pkg, net, cfgd["peak"])
             # one more step with the in-kernel device-clock stamps (a side figure; its atomics lengthen the launches, so it
             # is never mixed with the event timing above)
             lib.hh_profile_enable(net._h, 2)
             step(isolate=True)
             side.synchronize()
-            for c, d in collect_profile(pkg, net).items():
+            for c, d in collect_profile(pkg, net, cfgd["peak"]).items():
                 if c in per_cfg:
                     per_cfg[c]["kms"] = d["kms"] * per_cfg[c]["n"] / d["n"]
             lib.hh_profile_enable(net._h, 0)
@@ -316,8 +331,8 @@ def main():
     assert not bool(dec[3].any().item()), "decode flagged an image (solver guard / no-group fallback) on the bench maps"
 
     if rank == 0:
-        line = headline("images/sec (fwd+decode) HigherHRNet-W32 512px", world, B, args, elapsed, "bf16", {
-                "workload": f"HigherHRNet-W32 inference bf16, batch {B} @ 512x512 per GPU (conv fwd on N(0,1) images + AE decode "
+        line = headline(cfgd["metric"], world, B, args, elapsed, cfgd["dtype"], {
+                "workload": f"{cfgd['name']}, batch {B} @ {H}x{W} per GPU (conv fwd on N(0,1) images + AE decode "
                             f"on constructed maps, {args.people} people/image, det_thr 0.05, tag_thr 0.5, adjust+refine)",
                 "global_batch": world * B,
                 "parallelism": f"image-sharded replicas x{world}, no data-path collective",
@@ -337,7 +352,7 @@ def main():
                      102: "stem_conv_kernel (fp32 NCHW -> conv3x3 s2 3->64 + BN + ReLU -> bf16 NHWC)",
                      101: "junction_kernel (stage-0 conv3 1x1 [+downsample] + residual + ReLU + next conv1 1x1 + ReLU)"}.get(dom, str(dom))
             if lib.hh_conv_config(dom, cfgv) == 0:
-                kname = "conv_mfma_kernel<KS=%d,S=%d,KC=%d,NT=%d,WC=%d,PT=%d,TW=%d>" % tuple(cfgv)
+                kname = ("conv_fp8_kernel" if dom >= 1000 else "conv_mfma_kernel") + "<KS=%d,S=%d,KC=%d,NT=%d,WC=%d,PT=%d,TW=%d>" % tuple(cfgv)
             # Per-launch duration = the dispatch packet's begin .. end timestamps, delivered through the start / stop events of
             # hipExtLaunchKernelGGL on the launch stream: the quantity rocprofv3's kernel trace reports (serial pass in
             # profiles/rNN_bench_kernel_stats.csv).  The kernel's own first-workgroup-start .. last-workgroup-end on the device
@@ -347,9 +362,9 @@ def main():
             line["roofline"] = {
                 "bound": "mfma",
                 "achieved": round(achieved, 2),
-                "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                "peak": cfgd["peak"],
                 "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                "frac": round(achieved / cfgd["peak"], 4),
                 "traffic": traffic_for(kname),
                 "kernel": kname,
                 "launches": d["n"],
@@ -371,14 +386,14 @@ def main():
             }
         # decode half against the HBM roofline: compulsory bytes (read every network output once) over the
         # time of one hh_decode call alone; the kernels are latency/VALU bound by design, so this is small
-        dec_bytes = 6684672.0 * B
+        dec_bytes = 4.0 * K * ((H // 4) * (W // 4) * 2 + (H // 2) * (W // 2)) * B  # 6,684,672 B per 512x512 image
         line["decode_roofline"] = {
             "bound": "hbm", "achieved": round(dec_bytes / parts[1] / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(dec_bytes / parts[1] / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic_for("hh_decode (all kernels of one call)"),
             "algorithmic_bytes_per_call": dec_bytes, "ms_per_call": round(parts[1] * 1e3, 3),
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: the other ranks would idle at the final barrier
-            line["cpu_baseline"] = cpu_baseline(pkg, sd, uniq)
+            line["cpu_baseline"] = cpu_baseline(pkg, sd, uniq, fwd_images=4 if H <= 512 else 2, size=H)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

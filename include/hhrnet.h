@@ -22,6 +22,9 @@ extern "C" {
 
 #define HH_ABI_VERSION 2
 #define HH_DTYPE_BF16 1 /* bf16 MFMA operands, fp32 accumulate, bf16 NHWC activations */
+#define HH_DTYPE_FP8 2  /* OCP e4m3 MFMA operands (v_mfma_f32_32x32x64_f8f6f4), fp32 accumulate, e4m3 NHWC activations with one
+                           scale per tensor, e4m3 weights with one scale per output channel; needs hh_calibrate (BASELINE.json
+                           configs[4]; no reference precedent: the reference infers in fp32, keypoints/model.py:79-83)     */
 
 typedef struct hh_net hh_net;
 typedef struct hh_decoder hh_decoder;
@@ -53,6 +56,17 @@ int hh_load_weights(hh_net *net, const char *name, const float *host, const int6
 /* Folds eval-mode BatchNorm (eps 1e-5) into the preceding conv, packs bf16 kernel-layout
  * weights and uploads them.  Fails if any parameter was never loaded.  Synchronous.     */
 int hh_finalize(hh_net *net);
+
+/* fp8 handles only: sets the per-tensor activation scales from `rounds` (0 = 2) forwards over a calibration batch
+ * (images [B,3,H,W] fp32 NCHW, device).  Every layer's output maximum is taken from its fp32 epilogue values and mapped to
+ * 240 of e4m3's 448; maxima accumulate over calls until the next hh_finalize.  Synchronous.  hh_forward on an fp8 handle
+ * fails until this has run.                                                                                              */
+int hh_calibrate(hh_net *net, const float *images, int B, int H, int W, int rounds, void *stream);
+
+/* The host-side OCP e4m3fn codec the fp8 weight packer uses (round to nearest even, saturating at +-448, NaN = 0x7f);
+ * exported so that it can be checked against an independent implementation without a GPU.                                */
+int hh_e4m3_encode(const float *x, int64_t n, unsigned char *out);
+int hh_e4m3_decode(const unsigned char *x, int64_t n, float *out);
 
 /* Allocates the activation workspace for inputs up to [B,3,H,W] (H, W multiples of 32).
  * Synchronous; hh_forward calls it implicitly when the shape grows.                     */

@@ -43,6 +43,9 @@ def _sig(lib):
         "hh_param_shape": (i32, [vp, i32, pi64]),
         "hh_load_weights": (i32, [vp, cp, vp, pi64, i32]),
         "hh_finalize": (i32, [vp]),
+        "hh_calibrate": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+        "hh_e4m3_encode": (i32, [vp, i64, vp]),
+        "hh_e4m3_decode": (i32, [vp, i64, vp]),
         "hh_reserve": (i32, [vp, i32, i32, i32]),
         "hh_workspace_bytes": (i64, [vp]),
         "hh_forward": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, vp]),

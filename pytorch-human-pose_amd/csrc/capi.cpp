@@ -16,7 +16,7 @@ const char *hh_last_error(void) { return hh_get_error(); }
 
 hh_net *hh_create(int num_kpts, int C, int dtype)
 {
-    if (dtype != HH_DTYPE_BF16) { hh_set_error("hh_create: only HH_DTYPE_BF16 is implemented"); return nullptr; }
+    if (dtype != HH_DTYPE_BF16 && dtype != HH_DTYPE_FP8) { hh_set_error("hh_create: dtype must be HH_DTYPE_BF16 or HH_DTYPE_FP8"); return nullptr; }
     if (num_kpts <= 0 || num_kpts > 64 || C <= 0 || C % 16) { hh_set_error("hh_create: need 0 < num_kpts <= 64 and C % 16 == 0"); return nullptr; }
     hh_net *n = new hh_net();
     n->K = num_kpts; n->C = C; n->dtype = dtype;
@@ -68,7 +68,22 @@ int hh_load_weights(hh_net *net, const char *name, const float *host, const int6
     net->finalized = false;
     return 0;
 }
+int hh_e4m3_encode(const float *x, int64_t n, unsigned char *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = hh_f32_to_e4m3(x[i]);
+    return 0;
+}
+int hh_e4m3_decode(const unsigned char *x, int64_t n, float *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = hh_e4m3_to_f32(x[i]);
+    return 0;
+}
 int hh_finalize(hh_net *net) { return net->finalize(); }
+int hh_calibrate(hh_net *net, const float *images, int B, int H, int W, int rounds, void *stream)
+{
+    if (!images || B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) { hh_set_error("hh_calibrate: need images [B,3,H,W] with H, W multiples of 32"); return 1; }
+    return net->calibrate(images, B, H, W, rounds > 0 ? rounds : 2, (hipStream_t)stream);
+}
 int hh_reserve(hh_net *net, int B, int H, int W) { return net->reserve(B, H, W); }
 int64_t hh_workspace_bytes(const hh_net *net) { return net->ws_bytes; }
 
@@ -128,6 +143,11 @@ int hh_profile_get(hh_net *net, int i, int *cfg, double *flops, double *bytes, f
 }
 int hh_conv_config(int cfg, int out[7])
 {
+    if (cfg >= 1000 && cfg - 1000 < conv_fp8_num_configs()) {  // fp8 instantiations are reported as 1000 + index
+        const Fp8ConvConfig &c = conv_fp8_config(cfg - 1000);
+        out[0] = c.KS; out[1] = c.S; out[2] = c.KC; out[3] = c.NT; out[4] = 1; out[5] = c.PT; out[6] = c.TW;
+        return 0;
+    }
     if (cfg < 0 || cfg >= conv_num_configs()) return 1;
     const ConvConfig &c = conv_config(cfg);
     out[0] = c.KS; out[1] = c.S; out[2] = c.KC; out[3] = c.NT; out[4] = c.WC; out[5] = c.PT; out[6] = c.TW;

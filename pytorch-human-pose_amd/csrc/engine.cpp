@@ -200,7 +200,7 @@ struct Builder {
     {
         for (int u = 0; u < 4; ++u) {
             const std::string up = prefix + "." + std::to_string(u);
-            if (C == 32) {  // fused kernel, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
+            if (C == 32 && n.dtype != 2) {  // fused kernel, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
                 Op o;
                 o.kind = OP_BB;
                 o.layer = L(up + ".conv1", up + ".bn1", C, C, 3, 1);
@@ -247,9 +247,16 @@ struct Builder {
         // single pass over the 256-channel tensor (bottleneck_junction.hip)
         auto unit = [&](int u) { return bb + ".stages.0.blocks.0.scales_blocks.0." + std::to_string(u); };
         cb(unit(0), "conv1", "bn1", 64, 64, 1, 1, X, t1, 1);
+        const int DS = n.dtype == 2 ? T(256, 2) : -1;  // fp8 path: the downsample branch of unit 0 is a tensor of its own
         for (int u = 0; u < 4; ++u) {
             const std::string up = unit(u);
             cb(up, "conv2", "bn2", 64, 64, 3, 1, t1, t2, 1);
+            if (n.dtype == 2) {  // layer by layer (hrnet.py:58-74): downsample, conv3 + residual + ReLU, next unit's conv1
+                if (u == 0) cb(up, "downsample.0", "downsample.1", 64, 256, 1, 1, X, DS, 0);
+                cb(up, "conv3", "bn3", 64, 256, 1, 1, t2, Y, 1, u == 0 ? DS : Y);
+                if (u < 3) cb(unit(u + 1), "conv1", "bn1", 256, 64, 1, 1, Y, t1, 1);
+                continue;
+            }
             Op o;
             o.kind = OP_JUNC; o.lane = lane;
             o.layer2 = u == 0 ? L(up + ".downsample.0", up + ".downsample.1", 64, 256, 1, 1) : -1;
@@ -276,6 +283,7 @@ struct Builder {
 
         const int catC = round_up(C + 2 * K, 16);
         const int CAT = T(catC, 2, true);  // [feats | init heatmaps | zero pad] = torch.cat of higher_hrnet.py:73
+        n.tensors[CAT].shared_scale = true;
 
         const int nblocks[4] = {1, 1, 4, 3};
         for (int s = 1; s < 4; ++s) {
@@ -456,6 +464,7 @@ int hh_net::finalize()
     HH_CHECK_HIP(conv_init());
     HH_CHECK_HIP(bb_fused_init());
     HH_CHECK_HIP(junction_init());
+    if (dtype == 2 && kind != 0) { hh_set_error("hh_finalize: the fp8 path covers HigherHRNet only"); return 1; }
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -487,6 +496,7 @@ int hh_net::finalize()
             HH_CHECK_HIP(hipMemcpy(l.d_bias, shift.data(), 64 * 4, hipMemcpyHostToDevice));
             continue;
         }
+        if (dtype == 2) continue;  // e4m3 weights: finalize_fp8() below
         const int cin_pad0 = round_up(l.cin, 16), coutp = round_up(l.cout, 32);
         if (hh_family_pick(l.ks, l.stride, cin_pad0, coutp, &l.KC, &l.NT)) {
             hh_set_error("no kernel family for conv " + l.conv);
@@ -540,6 +550,7 @@ int hh_net::finalize()
     for (auto &g : graphs) hipGraphExecDestroy(g.exec);
     graphs.clear();
     finalized = true;
+    if (dtype == 2 && finalize_fp8()) { finalized = false; return 1; }
     return 0;
 }
 
@@ -570,14 +581,14 @@ int hh_net::reserve(int B, int H, int W)
         return 0;
     };
     for (auto &t : tensors) {
-        const size_t bytes = (size_t)nB * (nH >> t.shift) * (nW >> t.shift) * t.C * 2;
+        const size_t bytes = (size_t)nB * (nH >> t.shift) * (nW >> t.shift) * t.C * elem();
         if (alloc(bytes, (void **)&t.ptr)) return 1;
         if (t.zero_init) HH_CHECK_HIP(hipMemset(t.ptr, 0, bytes));
     }
     if (taps_enabled)
         for (auto &t : taps) {
             const TensorDesc &d = tensors[t.tensor];
-            if (alloc((size_t)nB * (nH >> d.shift) * (nW >> d.shift) * d.C * 2, (void **)&t.copy)) return 1;
+            if (alloc((size_t)nB * (nH >> d.shift) * (nW >> d.shift) * d.C * elem(), (void **)&t.copy)) return 1;
         }
     rB = nB; rH = nH; rW = nW;
     return 0;
@@ -614,7 +625,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
     // Lanes: the resolution branches of an HR block and the outputs of a fusion layer are independent, so they run
     // on separate HIP streams (forked from / joined to the caller's stream with events; the same calls become
     // DAG edges under hipGraph capture).  The small low-resolution launches then fill CUs the big ones leave idle.
-    const bool multi = multi_lane && !taps_enabled && !prof_enabled;
+    const bool multi = multi_lane && !taps_enabled && !prof_enabled && !calibrating;
     if (multi) {
         // The lanes take the PRIORITY of the caller's stream.  A caller on a highest-priority stream gets its whole forward
         // on high-priority queues (dependent launches follow each other faster there: forward 5.25 -> 4.98 ms at batch 32),
@@ -687,6 +698,10 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             p.images = images; p.w = l.d_w; p.bias = l.d_bias;
             p.out = tensors[op.out].ptr; p.out_cs = tensors[op.out].C;
             p.B = B; p.H = H; p.W = W;
+            if (dtype == 2) {
+                p.out_fp8 = (unsigned char *)tensors[op.out].ptr; p.out_inv_scale = 1.f / op.s_out;
+                if (calibrating) p.absmax = d_amax + (&op - ops.data());
+            }
             ProfRecord *pr = nullptr;
             if (prof_enabled) {
                 if (prof_used == prof.size()) {
@@ -708,6 +723,10 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             break;
         }
         case OP_UPADD: {
+            if (dtype == 2) {
+                if (enqueue_fp8_upadd(op, B, H, W, s)) return 1;
+                break;
+            }
             UpAddParams p{};
             const TensorDesc &b = tensors[op.in], &o = tensors[op.out];
             p.base = b.ptr; p.base_cs = b.C; p.base_coff = 0;
@@ -724,7 +743,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             if (!taps_enabled) break;
             const TapInfo &t = taps[op.tap];
             const TensorDesc &d = tensors[t.tensor];
-            HH_CHECK_HIP(hipMemcpyAsync(t.copy, d.ptr, (size_t)B * (H >> d.shift) * (W >> d.shift) * d.C * 2,
+            HH_CHECK_HIP(hipMemcpyAsync(t.copy, d.ptr, (size_t)B * (H >> d.shift) * (W >> d.shift) * d.C * elem(),
                                         hipMemcpyDeviceToDevice, s));
             break;
         }
@@ -801,6 +820,22 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             break;
         }
         case OP_CONV: {
+            if (dtype == 2) {
+                ProfRecord *pr = nullptr;
+                if (prof_enabled) {
+                    if (prof_used == prof.size()) {
+                        ProfRecord r{};
+                        HH_CHECK_HIP(hipEventCreate(&r.e0));
+                        HH_CHECK_HIP(hipEventCreate(&r.e1));
+                        prof.push_back(r);
+                    }
+                    pr = &prof[prof_used++];
+                    pr->op = (int)(&op - ops.data());
+                    pr->slot = -1;
+                }
+                if (enqueue_fp8_conv(op, B, H, W, o1, o2, s, pr)) return 1;
+                break;
+            }
             const ConvLayer &l = layers[op.layer];
             const TensorDesc &ti = tensors[op.in];
             ConvParams p{};
@@ -875,6 +910,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
 int hh_net::forward(const float *images, int B, int H, int W, float *o1, float *o2, int use_graph, hipStream_t s)
 {
     if (!finalized) { hh_set_error("hh_forward: call hh_finalize first"); return 1; }
+    if (dtype == 2 && !calibrated) { hh_set_error("hh_forward: fp8 handle without activation scales, call hh_calibrate first"); return 1; }
     if (B > rB || H > rH || W > rW || !tensors[0].ptr || (taps_enabled && !taps.empty() && !taps[0].copy))
         if (reserve(B, H, W)) return 1;
     lastB = B; lastH = H; lastW = W;
@@ -1017,7 +1053,9 @@ hh_net::~hh_net()
     for (auto &l : layers) {
         if (l.d_w) hipFree(l.d_w);
         if (l.d_bias) hipFree(l.d_bias);
+        if (l.d_mult) hipFree(l.d_mult);
     }
+    if (d_amax) hipFree(d_amax);
 }
 
 // fp32 NCHW host copy of a tap
@@ -1027,8 +1065,18 @@ int hh_tap_read_impl(hh_net *n, int index, float *host)
     const TapInfo &t = n->taps[index];
     const TensorDesc &d = n->tensors[t.tensor];
     const int B = n->lastB, h = n->lastH >> d.shift, w = n->lastW >> d.shift;
-    std::vector<bf16_raw> tmp((size_t)B * h * w * d.C);
     HH_CHECK_HIP(hipDeviceSynchronize());
+    if (n->dtype == 2) {  // e4m3 bytes * the tensor's scale at the tap
+        std::vector<unsigned char> q((size_t)B * h * w * d.C);
+        HH_CHECK_HIP(hipMemcpy(q.data(), t.copy, q.size(), hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < t.C; ++c)
+                for (int y = 0; y < h; ++y)
+                    for (int x = 0; x < w; ++x)
+                        host[(((size_t)b * t.C + c) * h + y) * w + x] = hh_e4m3_to_f32(q[(((size_t)b * h + y) * w + x) * d.C + t.coff + c]) * t.scale;
+        return 0;
+    }
+    std::vector<bf16_raw> tmp((size_t)B * h * w * d.C);
     HH_CHECK_HIP(hipMemcpy(tmp.data(), t.copy, tmp.size() * 2, hipMemcpyDeviceToHost));
     for (int b = 0; b < B; ++b)
         for (int c = 0; c < t.C; ++c)

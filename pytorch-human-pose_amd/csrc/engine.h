@@ -39,12 +39,17 @@ struct ConvLayer {
     int KC = 0, NT = 0, cin_pad = 0, ncg = 0;
     bf16_raw *d_w = nullptr;
     float *d_bias = nullptr;
+    // fp8 path: e4m3 weights with one scale per output channel; d_mult[co] = s_in * w_scale[co] is rewritten whenever the
+    // activation scales change (calibration)
+    std::vector<float> w_scale;
+    float *d_mult = nullptr;
 };
 
 struct TensorDesc {
     int C = 0, shift = 0;  // spatial dims = (H >> shift, W >> shift)
-    bf16_raw *ptr = nullptr;
+    bf16_raw *ptr = nullptr;  // bf16 elements, or e4m3 bytes on the fp8 path (C bytes per pixel)
     bool zero_init = false;
+    bool shared_scale = false;  // fp8: written in channel slices by several ops (torch.cat buffer): one scale for all of them
 };
 
 enum OpKind { OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC, OP_STEM };
@@ -67,12 +72,16 @@ struct Op {
     int lane = 0;     // execution lane (HIP stream): resolution branches / fusion outputs run concurrently
     int nlanes = 0;   // OP_JOIN: all-to-all barrier over lanes [0, nlanes)
     int dep_from = 0; // OP_DEP: `lane` waits for everything enqueued so far on lane dep_from
+    // fp8 path: tensor scales seen by this op (real value = e4m3 * scale), resolved from the calibration maxima
+    float s_in = 1.f, s_in2 = 1.f, s_res = 1.f, s_out = 1.f, s_up[3] = {1.f, 1.f, 1.f};
+    int amax_slot = -1;  // index into hh_net::d_amax of this op's output maximum
 };
 
 struct TapInfo {
     std::string name;
     int tensor, coff, C;
     bf16_raw *copy = nullptr;
+    float scale = 1.f;  // fp8: scale of the tensor at the tap's position in the plan
 };
 
 struct ProfRecord {
@@ -123,6 +132,12 @@ struct hh_net {
     std::vector<hipEvent_t> lane_events;
     size_t lane_events_used = 0;
     bool multi_lane = true;
+    // fp8 path (dtype == HH_DTYPE_FP8)
+    bool calibrated = false;      // activation scales set (hh_calibrate)
+    bool calibrating = false;     // the running forward records per-op output maxima
+    unsigned *d_amax = nullptr;   // [ops.size()] bits of max |y| per op (calibration forwards only)
+    std::vector<float> amax;      // host copy, kept over the calibration rounds (running maximum)
+    int elem() const { return dtype == 2 ? 1 : 2; }  // bytes per activation element
 
     int build();
     int check_plan(std::string *why) const;  // static RAW/WAR/WAW check of the multi-lane schedule
@@ -132,6 +147,11 @@ struct hh_net {
     int enqueue(const float *images, int B, int H, int W, float *o1, float *o2, hipStream_t s);
     int forward(const float *images, int B, int H, int W, float *o1, float *o2, int use_graph, hipStream_t s);
     double flops(int B, int H, int W) const;
+    int finalize_fp8();
+    int calibrate(const float *images, int B, int H, int W, int rounds, hipStream_t s);
+    int resolve_scales();  // amax -> per-op scales (plan order), d_mult of every layer
+    int enqueue_fp8_conv(const Op &op, int B, int H, int W, float *o1, float *o2, hipStream_t s, ProfRecord *pr);
+    int enqueue_fp8_upadd(const Op &op, int B, int H, int W, hipStream_t s);
     void release_workspace();
     ~hh_net();
 };
@@ -139,3 +159,9 @@ struct hh_net {
 // kernel-family / instantiation choice, shared with the standalone conv op of the training path (capi.cpp)
 int hh_family_pick(int ks, int stride, int cin_pad, int coutp, int *KC, int *NT);
 int hh_pick_config(int ks, int stride, int KC, int NT, int Wo);
+
+// fp8 (e4m3, OCP) helpers shared by the engine and the C-ABI
+unsigned char hh_f32_to_e4m3(float f);
+float hh_e4m3_to_f32(unsigned char v);
+int hh_fp8_family_pick(int cin, int cout, int *KC, int *NT);
+int hh_fp8_pick_config(int ks, int stride, int KC, int NT, int Wo);

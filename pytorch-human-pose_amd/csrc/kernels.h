@@ -77,6 +77,51 @@ void conv_dma_variant(int v, int *PT, int *TW);
 hipError_t conv_dma_init();
 hipError_t conv_dma_launch(int variant, ConvParams p, hipStream_t s);
 
+// ---- fp8 path (conv_fp8.hip): e4m3 NHWC activations with one scale per tensor, e4m3 weights with one scale per cout
+struct Fp8ConvParams {
+    const unsigned char *in;  // [B, Hin, Win, in_cs] e4m3
+    int in_cs, in_coff;       // pixel stride / first channel (bytes, multiples of 16)
+    int Hin, Win;
+    const unsigned char *w;   // packed [cout_group][cin_chunk][k-step][lane half][piece 0/1][COUT_T][16]
+    const float *mult;        // [ncg*COUT_T] s_in * s_w[co] (0 for padding couts)
+    const float *bias;        // [ncg*COUT_T] folded BN shift / conv bias
+    const unsigned char *res; // optional residual (e4m3), same pixel grid as `out`
+    int res_cs, res_coff;
+    float res_scale;
+    unsigned char *out;       // optional e4m3 NHWC output
+    int out_cs, out_coff;
+    float out_inv_scale;      // 1 / s_out
+    float *out_f32;           // optional fp32 NCHW output [B, cout_real, Hob, Wob]
+    int Hob, Wob;
+    int osy, ooy, osx, oox;
+    int Ho, Wo;
+    int cin;                  // padded input channels (multiple of KC)
+    int cout_real, cout_store;
+    int relu;
+    int pad_y, pad_x;
+    int B, tiles_x, tiles_y, ncg;
+    int nphase;
+    size_t phase_stride;      // bytes between the weight sets of two transposed-conv phases
+    unsigned *absmax;         // calibration: atomicMax of the bits of max |y| over the launch (NULL = off)
+};
+struct Fp8ConvConfig {
+    int KS, S, KC, NT, PT, TW;
+    // bytes per staged pixel: KC + padding to an ODD number of 16-byte slots (bank-conflict-free ds_read_b128 across pixels)
+    static constexpr int pixel_stride(int kc) { return ((kc / 16 + 1) | 1) * 16; }
+    int cout_t() const { return 32 * NT; }
+    int th() const { return 4 * PT * (32 / TW); }
+    int nstep() const { return (KS * KS * (KC / 16) + 3) / 4; }
+    size_t lds_bytes() const {
+        const int PH = (th() - 1) * S + KS, PW = (TW - 1) * S + KS;
+        const size_t patch = ((size_t)PH * PW * pixel_stride(KC) + 15) & ~(size_t)15;
+        return patch + (size_t)nstep() * 4 * cout_t() * 16;
+    }
+};
+int conv_fp8_num_configs();
+const Fp8ConvConfig &conv_fp8_config(int i);
+hipError_t conv_fp8_launch(int cfg_index, const Fp8ConvParams &p, hipStream_t stream);
+hipError_t conv_fp8_init();
+
 // Fused 32-channel BasicBlock (basicblock_fused.hip): out = relu(conv2(relu(conv1(in))) + in), BN folded.
 struct BBParams {
     const bf16_raw *in; int in_cs;   // [B,H,W,in_cs], channels 0..31
@@ -118,6 +163,9 @@ struct StemParams {
     bf16_raw *out; int out_cs;
     int B, H, W;              // H, W even
     unsigned long long *clk;  // optional device-clock probe
+    unsigned char *out_fp8;   // fp8 path: e4m3 NHWC output [B,H/2,W/2,out_cs bytes] instead of `out`, q = e4m3(y * out_inv_scale)
+    float out_inv_scale;
+    unsigned *absmax;         // fp8 calibration: atomicMax of the bits of max |y|
 };
 #define HH_CFG_STEM 102  // pseudo instantiation index used by the profiler
 hipError_t stem_conv_launch(const StemParams &p, hipStream_t s);
@@ -131,6 +179,16 @@ struct UpAddParams {
     int B, H, W, C, relu;
 };
 hipError_t launch_upadd(const UpAddParams &p, hipStream_t s);
+// the same on e4m3 tensors: out = e4m3(act(base * base_scale + sum_j up_j * up_scale[j]) * out_inv_scale); C multiple of 16
+struct UpAddFp8Params {
+    const unsigned char *base; int base_cs; float base_scale;
+    const unsigned char *up[3]; int up_cs[3]; int up_shift[3]; float up_scale[3]; int nup;
+    unsigned char *out; int out_cs;
+    float out_inv_scale;
+    int B, H, W, C, relu;
+    unsigned *absmax;
+};
+hipError_t launch_upadd_fp8(const UpAddFp8Params &p, hipStream_t s);
 
 // ClassificationHead tail: global average pool (bf16 NHWC -> fp32 [B,C]) and Linear (fp32)
 hipError_t launch_avgpool(const bf16_raw *in, int in_cs, float *out, int B, int HW, int C, hipStream_t s);

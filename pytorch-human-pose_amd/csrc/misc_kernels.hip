@@ -54,6 +54,73 @@ hipError_t launch_upadd(const UpAddParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- the same fusion sum on e4m3 tensors (fp8 path): every operand carries its tensor scale, the sum is formed in fp32 and
+// requantised with the output scale.  One thread = 16 channels (16 B) of one pixel.
+__device__ __forceinline__ void fp8x16_fma(const uint4 q, float s, float v[16])
+{
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const auto lo2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[d], false), hi2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[d], true);
+        v[4 * d + 0] = __builtin_fmaf(lo2[0], s, v[4 * d + 0]); v[4 * d + 1] = __builtin_fmaf(lo2[1], s, v[4 * d + 1]);
+        v[4 * d + 2] = __builtin_fmaf(hi2[0], s, v[4 * d + 2]); v[4 * d + 3] = __builtin_fmaf(hi2[1], s, v[4 * d + 3]);
+    }
+}
+__global__ __launch_bounds__(256) void upadd_fp8_kernel(const UpAddFp8Params p)
+{
+    const int cgn = p.C / 16;
+    const size_t total = (size_t)p.B * p.H * p.W * cgn;
+    float amax = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cg = (int)(i % cgn);
+        size_t pix = i / cgn;
+        const int x = (int)(pix % p.W);
+        const int y = (int)((pix / p.W) % p.H);
+        const int b = (int)(pix / ((size_t)p.W * p.H));
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0.f;
+        fp8x16_fma(*reinterpret_cast<const uint4 *>(p.base + pix * p.base_cs + cg * 16), p.base_scale, v);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < p.nup) {
+                const int sh = p.up_shift[j];
+                const size_t up = ((size_t)b * (p.H >> sh) + (y >> sh)) * (p.W >> sh) + (x >> sh);
+                fp8x16_fma(*reinterpret_cast<const uint4 *>(p.up[j] + up * p.up_cs[j] + cg * 16), p.up_scale[j], v);
+            }
+        unsigned w[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float f = v[4 * d + k];
+                if (p.relu) f = fmaxf(f, 0.f);
+                amax = fmaxf(amax, fabsf(f));
+                t[k] = __builtin_amdgcn_fmed3f(f * p.out_inv_scale, -448.f, 448.f);
+            }
+            int q = 0;
+            q = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], q, false);
+            q = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], q, true);
+            w[d] = (unsigned)q;
+        }
+        *reinterpret_cast<uint4 *>(p.out + pix * p.out_cs + cg * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (p.absmax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(p.absmax, __float_as_uint(amax));
+    }
+}
+hipError_t launch_upadd_fp8(const UpAddFp8Params &p, hipStream_t s)
+{
+    const size_t total = (size_t)p.B * p.H * p.W * (p.C / 16);
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(upadd_fp8_kernel, dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 // keypoints/model.py:86: torch.flip(x, [3])
 __global__ __launch_bounds__(256) void flip_images_kernel(const float *__restrict__ in, float *__restrict__ out, size_t rows,
                                                           int W)

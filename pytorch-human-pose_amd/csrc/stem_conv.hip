@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p)
         for (int g = 0; g < 4; ++g) bv[ct][g] = *reinterpret_cast<const float4 *>(p.bias + ct * 32 + 8 * g + 4 * h);
     __syncthreads();
 
+    float amax = 0.f;  // fp8 calibration: max y of this lane
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int row = wave * 2 + q;  // output row inside the tile
@@ -115,6 +116,30 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ct][kk]), __builtin_bit_cast(bf16x8, bf[kk]), acc, 0, 0, 0);
+            if (p.out_fp8) {  // fp8 path: ReLU, scale, e4m3; two half-wave exchanges give every lane 16 contiguous couts (16h..)
+                unsigned x[2], z[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float t[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float f = fmaxf(acc[8 * m + i], 0.f);
+                        amax = fmaxf(amax, valid ? f : 0.f);
+                        t[i] = fminf(f * p.out_inv_scale, 448.f);
+                    }
+                    int q = 0, q2 = 0;
+                    q = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], q, false); q = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], q, true);
+                    q2 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], q2, false); q2 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], q2, true);
+                    x[m] = (unsigned)q; z[m] = (unsigned)q2;
+                }
+                auto s0 = __builtin_amdgcn_permlane32_swap(x[0], z[0], false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(x[1], z[1], false, false);
+                auto a0 = __builtin_amdgcn_permlane32_swap(s0[0], s1[0], false, false);
+                auto a1 = __builtin_amdgcn_permlane32_swap(s0[1], s1[1], false, false);
+                unsigned char *d8 = p.out_fp8 + (((size_t)b * Ho + (valid ? oy : 0)) * Wo + (valid ? ox : 0)) * p.out_cs + ct * 32 + 16 * h;
+                if (valid) *reinterpret_cast<u32x4 *>(d8) = u32x4{a0[0], a1[0], a0[1], a1[1]};
+                continue;
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const unsigned x0 = pack_relu_bf16x2(acc[8 * m + 0], acc[8 * m + 1]), x1 = pack_relu_bf16x2(acc[8 * m + 2], acc[8 * m + 3]);
@@ -124,6 +149,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p)
                 if (valid) *reinterpret_cast<u32x4 *>(dst + ct * 32 + m * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
             }
         }
+    }
+    if (p.absmax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        if (lane == 0 && amax > 0.f) atomicMax(p.absmax, __float_as_uint(amax));
     }
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0 && blockIdx.x + 256 >= gridDim.x) atomicMax(p.clk + 1, wall_clock64());

@@ -110,12 +110,28 @@ class EngineModule(nn.Module):
 
 
 class HigherHRNet(EngineModule):
-    def __init__(self, num_kpts: int, C: int = 32):
+    """`dtype="bf16"` (default) or `"fp8"` (BASELINE.json configs[4]: OCP e4m3 MFMA operands and activations; an extension, the
+    reference has one precision).  An fp8 net needs `calibrate(images)` once after its weights are loaded."""
+
+    DTYPES = {"bf16": 1, "fp8": 2}
+
+    def __init__(self, num_kpts: int, C: int = 32, dtype: str = "bf16"):
         super().__init__()
         self.num_kpts = num_kpts
         self.C = C
         self.num_deconv_layers = 1
-        self._init_engine(higher_hrnet_rows(num_kpts, C), lambda lib: lib.hh_create(num_kpts, C, 1))
+        self.engine_dtype = dtype
+        code = self.DTYPES[dtype]
+        self._init_engine(higher_hrnet_rows(num_kpts, C), lambda lib: lib.hh_create(num_kpts, C, code))
+
+    def calibrate(self, images: Tensor, rounds: int = 2) -> None:
+        """fp8 only: per-tensor activation scales from forwards over `images` [B,3,H,W] (hh_calibrate).  Weight changes
+        (load_state_dict, optimizer steps) invalidate it."""
+        x = self._check_input(images)
+        B, _, H, W = x.shape
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.hh_calibrate(self._h, x.data_ptr(), B, H, W, rounds, stream))
 
     def forward_raw(self, images: Tensor, out: tuple[Tensor, Tensor] | None = None) -> tuple[Tensor, Tensor]:
         """-> (init_heatmaps [B,2K,H/4,W/4], deconv_heatmaps [B,K,H/2,W/2]) fp32.

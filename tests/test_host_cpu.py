@@ -235,3 +235,30 @@ def test_keypoints_model_init_weights_and_wrappers():
     assert set(model.state_dict()) == set(net.state_dict()) and model.device.type == "cpu"
     model.freeze()
     assert not any(p.requires_grad for p in net.parameters())
+
+
+def test_e4m3_codec_matches_torch_float8(pkg):
+    """The fp8 path's host quantiser (weights -> OCP e4m3fn) against torch's float8_e4m3fn conversion: all 256 codes decode
+    alike, and random / boundary values inside the finite range encode to the same byte (round to nearest even); beyond
+    +-448 this codec saturates where torch produces NaN."""
+    import torch
+    lib = pkg._lib.load()
+    codes = np.arange(256, dtype=np.uint8)
+    dec = np.empty(256, np.float32)
+    lib.hh_e4m3_decode(codes.ctypes.data, 256, dec.ctypes.data)
+    ref = torch.from_numpy(codes).view(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(np.isnan(dec), np.isnan(ref)) and np.array_equal(dec[~np.isnan(ref)], ref[~np.isnan(ref)])
+    rs = np.random.RandomState(0)
+    finite = np.sort(np.unique(np.abs(ref[~np.isnan(ref)])))
+    mids = (finite[:-1] + finite[1:]) / 2  # exact ties between neighbouring codes
+    x = np.concatenate([rs.uniform(-448, 448, 20000), rs.normal(0, 1, 20000), rs.normal(0, 0.01, 20000), finite, -finite, mids, -mids,
+                        np.nextafter(mids.astype(np.float32), np.float32(0)), np.nextafter(mids.astype(np.float32), np.float32(1e9)),
+                        [0.0, -0.0, 1e-12, 447.9, 448.0, 463.9]]).astype(np.float32)
+    enc = np.empty(x.size, np.uint8)
+    lib.hh_e4m3_encode(x.ctypes.data, x.size, enc.ctypes.data)
+    want = torch.from_numpy(x).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    assert np.array_equal(enc, want), np.nonzero(enc != want)[0][:10]
+    big = np.array([464.0, 1e6, -1e6, np.inf, -np.inf, np.nan], np.float32)
+    out = np.empty(big.size, np.uint8)
+    lib.hh_e4m3_encode(big.ctypes.data, big.size, out.ctypes.data)
+    assert out.tolist() == [0x7e, 0x7e, 0xfe, 0x7e, 0xfe, 0x7f]
