@@ -200,7 +200,7 @@ struct Builder {
     {
         for (int u = 0; u < 4; ++u) {
             const std::string up = prefix + "." + std::to_string(u);
-            if (C == 32 && n.dtype != 2) {  // fused kernel, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
+            if ((C == 32 || (C == 64 && !getenv("HH_NO_BB64"))) && n.dtype != 2) {  // fused kernels, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
                 Op o;
                 o.kind = OP_BB;
                 o.layer = L(up + ".conv1", up + ".bn1", C, C, 3, 1);
@@ -463,6 +463,7 @@ int hh_net::finalize()
         if (!p.loaded && !p.counter) { hh_set_error("hh_finalize: parameter never loaded: " + p.name); return 1; }
     HH_CHECK_HIP(conv_init());
     HH_CHECK_HIP(bb_fused_init());
+    HH_CHECK_HIP(bb64_fused_init());
     HH_CHECK_HIP(junction_init());
     if (dtype == 2 && kind != 0) { hh_set_error("hh_finalize: the fp8 path covers HigherHRNet only"); return 1; }
     {
@@ -809,14 +810,16 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 }
                 pr = &prof[prof_used++];
                 pr->op = (int)(&op - ops.data());
-                pr->cfg = HH_CFG_BB_FUSED;
+                const double Cb = l1.cout;
+                pr->cfg = l1.cout == 64 ? HH_CFG_BB64_FUSED : HH_CFG_BB_FUSED;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
                 if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 2 * pr->slot;
-                pr->flops = 2.0 * 2.0 * B * p.H * p.W * 32.0 * 32.0 * 9.0;
-                pr->bytes = 2.0 * B * p.H * p.W * 32 * 2 + 2.0 * 2 * 9 * 32 * 32;
+                pr->flops = 2.0 * 2.0 * B * p.H * p.W * Cb * Cb * 9.0;
+                pr->bytes = 2.0 * B * p.H * p.W * Cb * 2 + 2.0 * 2 * 9 * Cb * Cb;
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
             }
-            HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
+            if (l1.cout == 64) HH_CHECK_HIP(bb64_fused_launch(p, num_cus, s));
+            else HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
             break;
         }
         case OP_CONV: {
@@ -1018,7 +1021,8 @@ double hh_net::flops(int B, int H, int W) const
     for (const Op &op : ops) {
         if (op.kind == OP_BB) {
             const TensorDesc &ti = tensors[op.in];
-            macs += 2.0 * (double)(H >> ti.shift) * (W >> ti.shift) * 32.0 * 32.0 * 9.0;
+            const double Cb = layers[op.layer].cout;
+            macs += 2.0 * (double)(H >> ti.shift) * (W >> ti.shift) * Cb * Cb * 9.0;
             continue;
         }
         if (op.kind == OP_STEM) { macs += (double)(H / 2) * (W / 2) * 27.0 * 64.0; continue; }

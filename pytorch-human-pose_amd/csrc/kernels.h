@@ -138,6 +138,10 @@ struct BBParams {
 #define HH_CFG_BB_FUSED 100  // pseudo instantiation index used by the profiler
 hipError_t bb_fused_init();
 hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s);
+// the same block for the 64-channel branch (basicblock_fused_c64.hip): weights packed KS=3,S=1,KC=32,NT=2 ([chunk][tap][4][64][8])
+#define HH_CFG_BB64_FUSED 103
+hipError_t bb64_fused_init();
+hipError_t bb64_fused_launch(BBParams p, int num_cus, hipStream_t s);
 
 // Junction of two stage-0 Bottlenecks (bottleneck_junction.hip): y = relu(W3 t2 + shift (+ Wd x | + res)), t1 = relu(W1 y + shift1)
 struct JuncParams {
