@@ -221,6 +221,10 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="issue the decode on a second stream beside the forward instead of behind it (not the headline)")
     ap.add_argument("--sequential", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--chained", action="store_true",
+                    help="the decode consumes the forward's OWN outputs: the net gets the seeded pass-through weights (dense random "
+                         "channels + reserved channels that carry constructed heatmaps / tags encoded in the input images to the "
+                         "outputs, pkg.synth.synth_passthrough_*), so its maps hold --people people per image")
     ap.add_argument("--single-lane", action="store_true",
                     help="no internal branch streams: kernels run one after another (what the roofline probe and the "
                          "isolated-kernel rocprofv3 pass measure)")
@@ -257,10 +261,14 @@ def main():
     if args.train:
         return train_bench(args, pkg, dist, rank, world, dev)
     net = pkg.HigherHRNet(K, cfgd["C"], dtype=cfgd["dtype"])
-    sd = {k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()}
+    if args.chained:
+        sd = {k: torch.from_numpy(v) for k, v in pkg.synth.synth_passthrough_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, K, 0).items()}
+        images = torch.from_numpy(pkg.synth.synth_passthrough_images(B, H // 4, W // 4, args.people, K, seed=rank)[0]).to(dev)
+    else:
+        sd = {k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()}
+        images = torch.from_numpy(pkg.synth.synth_images(B, H, W, seed=rank)).to(dev)
     net.load_state_dict(sd)
     net.to(dev).eval()
-    images = torch.from_numpy(pkg.synth.synth_images(B, H, W, seed=rank)).to(dev)
     if cfgd["dtype"] == "fp8":  # activation scales from a calibration batch of the same distribution (other seed)
         net.calibrate(torch.from_numpy(pkg.synth.synth_images(8, H, W, seed=4242)).to(dev))
     uniq = [pkg.synth.synth_decode_maps(K, H // 4, W // 4, args.people, seed=1000 + rank * 8 + i)[:3] for i in range(8)]
@@ -284,7 +292,9 @@ def main():
         # forward, then decode behind it on the same stream: a step costs their sum.  --overlap: the two
         # halves have no data dependency (the decode consumes constructed maps), so the decode may run on a second stream.
         out = net.forward_raw(images, outs)
-        if args.overlap and not isolate:
+        if args.chained:  # decode what the forward just wrote: heatmaps = init[:, :K] / deconv, tags = init[:, K:]
+            dec = parser.decode_batch_device(out[0][:, :K], out[1], [out[0][:, K:]], adjust=True, refine=True)
+        elif args.overlap and not isolate:
             with torch.cuda.stream(side2):
                 dec = parser.decode_batch_device(hm_q, hm_h, [tags], adjust=True, refine=True)
         else:
@@ -332,8 +342,11 @@ def main():
 
     if rank == 0:
         line = headline(cfgd["metric"], world, B, args, elapsed, cfgd["dtype"], {
-                "workload": f"{cfgd['name']}, batch {B} @ {H}x{W} per GPU (conv fwd on N(0,1) images + AE decode "
-                            f"on constructed maps, {args.people} people/image, det_thr 0.05, tag_thr 0.5, adjust+refine)",
+                "workload": f"{cfgd['name']}, batch {B} @ {H}x{W} per GPU (" + (
+                                f"CHAINED: forward of the pass-through net on images that encode {args.people} constructed people each, "
+                                "AE decode of the forward's own outputs" if args.chained else
+                                f"conv fwd on N(0,1) images + AE decode on constructed maps, {args.people} people/image") +
+                            ", det_thr 0.05, tag_thr 0.5, adjust+refine)",
                 "global_batch": world * B,
                 "parallelism": f"image-sharded replicas x{world}, no data-path collective",
                 "people_decoded_per_batch": num_people,

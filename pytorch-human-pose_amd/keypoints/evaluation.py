@@ -32,12 +32,19 @@ def pack_coco_results(image_id: int, kpts_coords: np.ndarray, obj_scores: np.nda
     return results
 
 
-def evaluate_images(model, images, image_ids, rank: int = 0, world_size: int = 1, multi_scale=None) -> list[dict] | None:
+def evaluate_images(model, images, image_ids, rank: int = 0, world_size: int = 1, multi_scale=None, batch: int = 32) -> list[dict] | None:
     """evaluate_dataset (bin/eval.py:18-49) over in-memory images, sharded by image across ranks (§8e: contiguous
     slices, no data-path collective; the packed lists are gathered to rank 0, other ranks get None).
-    `multi_scale` = tuple of scales -> `model.call_multi_scale` (the cfg-4 extension) instead of `model(...)`."""
+    `multi_scale` = tuple of scales -> `model.call_multi_scale` (the cfg-4 extension) instead of `model(...)`.
+    `batch` > 1 routes the single-scale case through `model.infer_images` (identical per-image results, one forward and one
+    decode per shape bucket); `batch` = 1 is the reference's image-by-image loop."""
     local = []
-    for idx in shard_range(len(images), rank, world_size):
-        res = model.call_multi_scale(images[idx], None, multi_scale) if multi_scale else model(images[idx], None)
-        local += pack_coco_results(image_ids[idx], res.kpts_coords, res.obj_scores)
+    mine = list(shard_range(len(images), rank, world_size))
+    if multi_scale or batch <= 1:
+        for idx in mine:
+            res = model.call_multi_scale(images[idx], None, multi_scale) if multi_scale else model(images[idx], None)
+            local += pack_coco_results(image_ids[idx], res.kpts_coords, res.obj_scores)
+    else:  # batched behind the same per-image results: shape buckets of up to `batch` images per forward + decode
+        for idx, res in zip(mine, model.infer_images([images[i] for i in mine], max_batch=batch)):
+            local += pack_coco_results(image_ids[idx], res.kpts_coords, res.obj_scores)
     return gather_results(local)

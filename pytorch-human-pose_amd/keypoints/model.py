@@ -12,7 +12,7 @@ from torch import Tensor, nn
 
 from .. import _lib
 from .grouping import MPPEHeatmapParser
-from .results import InferenceKeypointsResult
+from .results import InferenceKeypointsResult, transform_coords
 import ctypes as C
 
 from .transforms_utils import COCO_FLIP_INDEX, IMAGENET_MEAN, IMAGENET_STD, affine_matrix, get_multi_scale_size
@@ -266,6 +266,90 @@ class InferenceKeypointsModel:
             out = fn()
         cur.wait_stream(self._stream)
         return out
+
+    def _geometry(self, image: np.ndarray):
+        """Resize-align geometry of one raw image: ((w, h) of the model input, center, scale, destination->source 2x3 matrix)."""
+        size, center, scale = get_multi_scale_size(image, self.input_size, 1, 1)
+        fwd = np.vstack([affine_matrix(center, scale, size), [0, 0, 1]])
+        return size, center, scale, np.ascontiguousarray(np.linalg.inv(fwd)[:2], dtype=np.float64)
+
+    @torch.no_grad()
+    def infer_images(self, raw_images: list[np.ndarray], annots: list | None = None, max_batch: int = 32) -> list[InferenceKeypointsResult]:
+        """The batched path behind the reference's single-image interface (`__call__` per image, bin/eval.py:18-49): images are
+        bucketed by model-input shape, every bucket runs as batches of up to `max_batch` -- ONE host->device copy of the raw
+        uint8 pixels, hh_preprocess_u8 per image into one [B,3,h,w] tensor, one (flip-TTA) forward, one hh_decode, one
+        device->host copy of the small result arrays -- and every image gets the result `self(image, annot)` returns
+        (same kernels on the same per-image data: images of a batch are independent)."""
+        n = len(raw_images)
+        annots = annots if annots is not None else [None] * n
+        geo = [self._geometry(img) for img in raw_images]
+        buckets: dict[tuple, list[int]] = {}
+        for i, g in enumerate(geo):
+            buckets.setdefault(tuple(g[0]), []).append(i)
+        results: list = [None] * n
+        mean, std = IMAGENET_MEAN.ctypes.data_as(C.POINTER(C.c_float)), IMAGENET_STD.ctypes.data_as(C.POINTER(C.c_float))
+
+        def finish(job):
+            """device -> host results of one enqueued batch, un-warp, result objects"""
+            chunk, (w, h), x, hms, tags, host_out, done = job
+            done.synchronize()
+            lists = self._parser.to_lists(*host_out)
+            self.model_input_shape = (h, w)
+            for j, i in enumerate(chunk):
+                joints, scores = lists[j]
+                coords = transform_coords(joints[..., :2], geo[i][1], geo[i][2], (w, h))
+                results[i] = InferenceKeypointsResult(raw_images[i], annots[i], x[j], coords, joints[..., 2], joints[..., 3:], scores,
+                                                      self.det_thr, self.tag_thr, self.limbs, [t[j:j + 1] for t in hms],
+                                                      [t[j:j + 1] for t in tags])
+
+        # Two-deep software pipeline: while the GPU works on batch k the host stages the pixels of batch k+1 into a pinned
+        # buffer and only then collects the results of batch k (two staging buffers, each guarded by the event of its last use).
+        stage = [None, None]
+        stage_free: list = [None, None]
+        pending = None
+        turn = 0
+        for (w, h), idxs in buckets.items():
+            for lo in range(0, len(idxs), max_batch):
+                chunk = idxs[lo:lo + max_batch]
+                sizes = [raw_images[i].size for i in chunk]
+                offs = np.cumsum([0] + sizes)
+                if stage[turn] is None or stage[turn].numel() < offs[-1]:
+                    stage[turn] = torch.empty(int(offs[-1]), dtype=torch.uint8).pin_memory()
+                elif stage_free[turn] is not None:
+                    stage_free[turn].synchronize()  # the copy that last read this buffer has finished
+                host = stage[turn]
+                hview = host.numpy()
+                for j, i in enumerate(chunk):
+                    np.copyto(hview[offs[j]:offs[j + 1]].reshape(raw_images[i].shape), raw_images[i], casting="same_kind")
+
+                def run(chunk=chunk, host=host, offs=offs, w=w, h=h):
+                    raw = host[: int(offs[-1])].to(self.device, non_blocking=True)
+                    copied = torch.cuda.Event()
+                    copied.record()
+                    x = torch.empty((len(chunk), 3, h, w), device=self.device, dtype=torch.float32)
+                    stream = torch.cuda.current_stream(x.device).cuda_stream
+                    with torch.cuda.device(x.device):
+                        for j, i in enumerate(chunk):
+                            img = raw_images[i]
+                            _lib.check(self._lib.hh_preprocess_u8(raw.data_ptr() + int(offs[j]), img.shape[0], img.shape[1],
+                                                                  geo[i][3].ctypes.data_as(C.POINTER(C.c_double)), x[j].data_ptr(), h, w,
+                                                                  mean, std, stream))
+                    hms, tags = self.forward_tta(x)
+                    out = self._parser.decode_batch_device(hms[0], hms[1], tags, adjust=True, refine=True)
+                    host_out = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True) for t in out]
+                    done = torch.cuda.Event()
+                    done.record()
+                    return (chunk, (w, h), x, hms, tags, host_out, done), copied, raw
+
+                job, copied, _raw = self._on_fast_stream(run)
+                stage_free[turn] = copied
+                turn ^= 1
+                if pending is not None:
+                    finish(pending)
+                pending = job
+        if pending is not None:
+            finish(pending)
+        return results
 
     def __call__(self, raw_image: np.ndarray, annot: list | None) -> InferenceKeypointsResult:
         """model.py:78-111"""

@@ -172,3 +172,124 @@ def edit_loss_case(tag: str, joints):
         joints[0][1][1, :, 2] = 0
         joints[0][1][1, 3] = (4, 4, 1)
     return joints
+
+
+# ----------------------------------------------------------------------------------------
+# "Pass-through" HigherHRNet: seeded dense weights like synth_param, except that a few RESERVED channels carry values of the
+# input image unchanged to the outputs, so that forward + decode can be exercised (and timed) as ONE chain on person-like
+# maps without a trained checkpoint (none is available offline).  Every 4x4x3 block of the image holds, for its quarter-res
+# pixel, the K heatmap values and one tag value; the two stem convs gather them into channels 0..K of the 64-channel
+# tensor (one-hot taps), residual units are identities on the reserved channels (their conv rows are zero and every value
+# is >= 0, so relu(0 + x) = x), the transition / fusion layers copy them, the 1x1 head reads them out (all K tag maps =
+# the one tag channel) and the transposed conv carries the bilinear x2 kernel [.25 .75 .75 .25]^2 for the half-res
+# heatmaps.  All other channels keep their random dense weights (they read the reserved channels but never write them),
+# so the arithmetic the chip performs -- and the clock it holds -- is that of a dense net.
+# ----------------------------------------------------------------------------------------
+def synth_passthrough_state_dict(shapes: dict, num_kpts: int = 17, seed: int = 0) -> dict:
+    K, R = num_kpts, num_kpts + 1  # reserved channels 0..K-1 = heatmaps, K = tag field
+    sd = {k: synth_param(k, s, seed).copy() for k, s in shapes.items()}
+
+    def bn_identity(prefix, chans):
+        for c in chans:
+            sd[prefix + ".weight"][c] = 1.0
+            sd[prefix + ".bias"][c] = 0.0
+            sd[prefix + ".running_mean"][c] = 0.0
+            sd[prefix + ".running_var"][c] = 1.0 - 1e-5
+
+    def slot(v):  # value v of a quarter-res pixel sits at (dy, dx, ch) of its 4x4x3 image block
+        return v // 12, (v // 3) % 4, v % 3
+
+    # stem: image block -> 12 half-res channels ((dy&1, dx&1, ch)) -> R quarter-res channels
+    w1, w2 = sd["backbone.conv1.weight"], sd["backbone.conv2.weight"]
+    w1[:12] = 0.0
+    for a in range(2):
+        for b in range(2):
+            for ch in range(3):
+                w1[(a * 2 + b) * 3 + ch, ch, 1 + a, 1 + b] = 1.0
+    bn_identity("backbone.bn1", range(12))
+    w2[:R] = 0.0
+    for v in range(R):
+        dy, dx, ch = slot(v)
+        w2[v, ((dy & 1) * 2 + (dx & 1)) * 3 + ch, 1 + (dy >> 1), 1 + (dx >> 1)] = 1.0
+    bn_identity("backbone.bn2", range(R))
+    for key in list(sd):
+        w = sd[key]
+        # residual units: the last conv of every unit writes nothing into the reserved channels
+        if key.endswith((".conv2.weight", ".conv3.weight")) and ".scales_blocks." in key or ".resid_blocks." in key and key.endswith(".conv2.weight"):
+            if ".stages.0." in key and key.endswith(".conv2.weight"):
+                continue  # Bottleneck: conv2 is the middle conv, conv3 the last
+            w[:R] = 0.0
+            bn_identity(key.replace(".conv", ".bn").rsplit(".", 1)[0], range(R))
+        # fusion terms into output scale 0 (1x1 conv + BN at low resolution, upsampled and added)
+        if ".scales_fusion_layers.0." in key and key.endswith(".0.weight"):
+            w[:R] = 0.0
+            bn_identity(key.rsplit(".", 2)[0] + ".1", range(R))
+    # stage 0, unit 0: the downsample branch carries the reserved channels from the 64- to the 256-channel tensor
+    ds = "backbone.stages.0.blocks.0.scales_blocks.0.0.downsample"
+    sd[ds + ".0.weight"][:R] = 0.0
+    for v in range(R):
+        sd[ds + ".0.weight"][v, v, 0, 0] = 1.0
+    bn_identity(ds + ".1", range(R))
+    # transition into branch 0: centre tap copy
+    tr = "backbone.stages.0.transition_layer.transition_blocks.0"
+    sd[tr + ".0.weight"][:R] = 0.0
+    for v in range(R):
+        sd[tr + ".0.weight"][v, v, 1, 1] = 1.0
+    bn_identity(tr + ".1", range(R))
+    # heads
+    C = sd["init_heatmaps_head.weight"].shape[1]
+    hw = sd["init_heatmaps_head.weight"]
+    hw[:] = 0.0
+    sd["init_heatmaps_head.bias"][:] = 0.0
+    for k in range(K):
+        hw[k, k, 0, 0] = 1.0       # heatmap k
+        hw[K + k, K, 0, 0] = 1.0   # tag map k = the tag channel
+    dw = sd["deconv_layers.0.deconv.0.weight"]  # [C + 2K, C, 4, 4]
+    dw[:, :K] = 0.0
+    b = np.array([0.25, 0.75, 0.75, 0.25], np.float32)
+    for k in range(K):
+        dw[C + k, k] = np.outer(b, b)
+    bn_identity("deconv_layers.0.deconv.1", range(K))
+    fw = sd["deconv_layers.0.final_layer.weight"]
+    fw[:] = 0.0
+    sd["deconv_layers.0.final_layer.bias"][:] = 0.0
+    for k in range(K):
+        fw[k, k, 0, 0] = 1.0
+    return sd
+
+
+def synth_passthrough_images(batch: int, hq: int, wq: int, num_people, num_kpts: int = 17, seed: int = 0):
+    """Images [B,3,4hq,4wq] for a pass-through net: constructed quarter-res heatmaps (synth_decode_maps) and one tag field per
+    image (per pixel the tag of the strongest blob there), rounded to bf16-exact values, written into the reserved slots of
+    every 4x4x3 block; all other pixels ~ N(0,1).  Returns (images, hm_q [B,K,hq,wq], tag_field [B,hq,wq])."""
+    K = num_kpts
+    rs = np.random.RandomState(77 + seed)
+    images = rs.standard_normal((batch, 3, 4 * hq, 4 * wq)).astype(np.float32)
+    hms = np.zeros((batch, K, hq, wq), np.float32)
+    fields = np.zeros((batch, hq, wq), np.float32)
+    yq, xq = np.mgrid[0:hq, 0:wq].astype(np.float32)
+
+    def bf16(a):  # round to nearest even to bf16, back to fp32
+        u = a.astype(np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).view(np.float32)
+
+    for i in range(batch):
+        P = num_people[i % len(num_people)] if isinstance(num_people, (list, tuple)) else num_people
+        hm_q, _, _, people = synth_decode_maps(K, hq, wq, P, seed=seed * 1000 + i)
+        field = np.abs(0.05 * rs.standard_normal((hq, wq))).astype(np.float32)
+        best = np.zeros((hq, wq), np.float32)
+        for p in range(P):
+            for k in range(K):
+                x, y, amp = people[p, k]
+                if amp == 0:
+                    continue
+                g = amp * np.exp(-((xq - x) ** 2 + (yq - y) ** 2) / (2 * 2.0**2))
+                m = (g > 0.05 * amp) & (g > best)
+                field[m] = 1.7 * (p + 1) + 0.05 * rs.standard_normal(int(m.sum()))
+                best = np.maximum(best, g)
+        hms[i], fields[i] = bf16(hm_q), bf16(field)
+        vals = np.concatenate([hms[i], fields[i][None]], 0)  # [K+1,hq,wq]
+        for v in range(K + 1):
+            dy, dx, ch = v // 12, (v // 3) % 4, v % 3
+            images[i, ch, dy::4, dx::4] = vals[v]
+    return images, hms, fields

@@ -211,3 +211,20 @@ def test_train_mode_oracle_matches_reference_forward_and_autograd(synth):
         np.testing.assert_allclose(np.linalg.norm(gr.astype(np.float64)), g["grad.norms"][i], rtol=2e-3, atol=1e-7)
         np.testing.assert_allclose(gr[np.linspace(0, gr.size - 1, 4).astype(int)], g["grad.samples"][i], rtol=5e-3,
                                    atol=2e-3 * g["grad.norms"][i] / max(np.sqrt(gr.size), 1.0) + 1e-9)
+
+
+def test_passthrough_net_carries_constructed_maps_through_the_oracle(pkg, synth):
+    """The seeded "pass-through" weights (synth.synth_passthrough_state_dict: dense random weights whose reserved channels
+    carry image values to the outputs) make HigherHRNet.forward emit the constructed person-like maps: exactly for the
+    quarter-res heatmaps and tags, the bilinear x2 of them for the half-res heatmaps.  This is the net the chained
+    forward -> decode test and `bench.py --chained` run."""
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_passthrough_state_dict({k: tuple(v.shape) for k, v in _synth_sd(synth, pkg, 32, 0).items()}, 17, 0).items()}
+    imgs, hms, fields = synth.synth_passthrough_images(2, 32, 32, [3, 5], 17, 0)
+    with torch.no_grad():
+        (hq, hh), tags = ofw.higher_hrnet(torch.from_numpy(imgs), sd, 17)
+    assert np.array_equal(hq.numpy(), hms) and np.array_equal(tags.numpy(), np.repeat(fields[:, None], 17, 1))
+    up = torch.nn.functional.interpolate(torch.from_numpy(hms), scale_factor=2, mode="bilinear", align_corners=False).numpy()
+    assert np.array_equal(hh.numpy()[:, :, 2:-2, 2:-2], up[:, :, 2:-2, 2:-2])
+    for b, people in enumerate((3, 5)):
+        j, s = orc.decode(hq[b].numpy(), hh[b].numpy(), [tags[b].numpy()], max_people=30, det_thr=0.05, tag_thr=0.5)
+        assert people <= j.shape[0] <= 3 * people and (s > 0.3).sum() >= people - 1  # the constructed people come out as strong groups

@@ -1,0 +1,24 @@
+"""Images/sec through the reference-style API (GPU box): python tools/api_throughput.py [n_images] [flip]
+InferenceKeypointsModel(image) one by one vs InferenceKeypointsModel.infer_images(list) on 512x512 uint8 images with
+person-like content is not available without a trained checkpoint, so the net has the seeded synthetic weights (its maps
+make the decode run its worst case: every candidate passes det_thr) -- compare with bench.py's forward+decode figure."""
+import importlib, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("pytorch-human-pose_amd")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+flip = len(sys.argv) > 2 and sys.argv[2] == "flip"
+net = pkg.HigherHRNet(17, 32)
+net.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()})
+model = pkg.InferenceKeypointsModel(net, det_thr=0.05, tag_thr=0.5, use_flip=flip, input_size=512, device="cuda:0")
+rs = np.random.RandomState(0)
+images = [rs.randint(0, 255, (512, 512, 3)).astype(np.uint8) for _ in range(n)]
+model.infer_images(images[:64])
+torch.cuda.synchronize(); t0 = time.perf_counter()
+res = model.infer_images(images)
+torch.cuda.synchronize(); t1 = time.perf_counter() - t0
+for im in images[:4]: model(im, None)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for im in images[:32]: model(im, None)
+torch.cuda.synchronize(); t2 = (time.perf_counter() - t0) / 32
+print(f"infer_images: {n / t1:.1f} img/s ({t1 / n * 1e3:.3f} ms/img, flip={flip}); single calls: {1 / t2:.1f} img/s ({t2 * 1e3:.2f} ms/img)")
