@@ -322,10 +322,18 @@ class InferenceKeypointsModel:
                 for j, i in enumerate(chunk):
                     np.copyto(hview[offs[j]:offs[j + 1]].reshape(raw_images[i].shape), raw_images[i], casting="same_kind")
 
-                def run(chunk=chunk, host=host, offs=offs, w=w, h=h):
+                # host -> device on a copy stream of its own, so that the pixels of this batch cross PCIe while the previous
+                # batch still computes (25 MB per batch of 32 512x512 images: ~1.7 ms that would otherwise sit on the compute stream)
+                if getattr(self, "_copy_stream", None) is None:
+                    self._copy_stream = torch.cuda.Stream(self.device)
+                with torch.cuda.stream(self._copy_stream):
                     raw = host[: int(offs[-1])].to(self.device, non_blocking=True)
                     copied = torch.cuda.Event()
                     copied.record()
+
+                def run(chunk=chunk, raw=raw, copied=copied, offs=offs, w=w, h=h):
+                    torch.cuda.current_stream(self.device).wait_event(copied)
+                    raw.record_stream(torch.cuda.current_stream(self.device))
                     x = torch.empty((len(chunk), 3, h, w), device=self.device, dtype=torch.float32)
                     stream = torch.cuda.current_stream(x.device).cuda_stream
                     with torch.cuda.device(x.device):

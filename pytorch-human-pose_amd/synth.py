@@ -185,7 +185,7 @@ def edit_loss_case(tag: str, joints):
 # heatmaps.  All other channels keep their random dense weights (they read the reserved channels but never write them),
 # so the arithmetic the chip performs -- and the clock it holds -- is that of a dense net.
 # ----------------------------------------------------------------------------------------
-def synth_passthrough_state_dict(shapes: dict, num_kpts: int = 17, seed: int = 0) -> dict:
+def synth_passthrough_state_dict(shapes: dict, num_kpts: int = 17, seed: int = 0, tag_gain: float = 1.0) -> dict:
     K, R = num_kpts, num_kpts + 1  # reserved channels 0..K-1 = heatmaps, K = tag field
     sd = {k: synth_param(k, s, seed).copy() for k, s in shapes.items()}
 
@@ -243,7 +243,7 @@ def synth_passthrough_state_dict(shapes: dict, num_kpts: int = 17, seed: int = 0
     sd["init_heatmaps_head.bias"][:] = 0.0
     for k in range(K):
         hw[k, k, 0, 0] = 1.0       # heatmap k
-        hw[K + k, K, 0, 0] = 1.0   # tag map k = the tag channel
+        hw[K + k, K, 0, 0] = tag_gain   # tag map k = the tag channel (x tag_gain: uint8 images can only carry values up to ~2.2)
     dw = sd["deconv_layers.0.deconv.0.weight"]  # [C + 2K, C, 4, 4]
     dw[:, :K] = 0.0
     b = np.array([0.25, 0.75, 0.75, 0.25], np.float32)
@@ -258,7 +258,7 @@ def synth_passthrough_state_dict(shapes: dict, num_kpts: int = 17, seed: int = 0
     return sd
 
 
-def synth_passthrough_images(batch: int, hq: int, wq: int, num_people, num_kpts: int = 17, seed: int = 0):
+def synth_passthrough_images(batch: int, hq: int, wq: int, num_people, num_kpts: int = 17, seed: int = 0, tag_gain: float = 1.0):
     """Images [B,3,4hq,4wq] for a pass-through net: constructed quarter-res heatmaps (synth_decode_maps) and one tag field per
     image (per pixel the tag of the strongest blob there), rounded to bf16-exact values, written into the reserved slots of
     every 4x4x3 block; all other pixels ~ N(0,1).  Returns (images, hm_q [B,K,hq,wq], tag_field [B,hq,wq])."""
@@ -288,8 +288,18 @@ def synth_passthrough_images(batch: int, hq: int, wq: int, num_people, num_kpts:
                 field[m] = 1.7 * (p + 1) + 0.05 * rs.standard_normal(int(m.sum()))
                 best = np.maximum(best, g)
         hms[i], fields[i] = bf16(hm_q), bf16(field)
-        vals = np.concatenate([hms[i], fields[i][None]], 0)  # [K+1,hq,wq]
+        vals = np.concatenate([hms[i], fields[i][None] / tag_gain], 0)  # [K+1,hq,wq]
         for v in range(K + 1):
             dy, dx, ch = v // 12, (v // 3) % 4, v % 3
             images[i, ch, dy::4, dx::4] = vals[v]
     return images, hms, fields
+
+
+def synth_passthrough_raw_u8(batch: int, hq: int, wq: int, num_people, num_kpts: int = 17, seed: int = 0, tag_gain: float = 8.0):
+    """The same as raw uint8 HWC images for InferenceKeypointsModel (ToTensor + ImageNet normalisation undone and rounded to
+    pixel values: the encoded values are quantised to ~0.017, the tag channel is stored / tag_gain to fit the pixel range)."""
+    mean = np.array([0.485, 0.456, 0.406], np.float32)[:, None, None]
+    std = np.array([0.229, 0.224, 0.225], np.float32)[:, None, None]
+    x = synth_passthrough_images(batch, hq, wq, num_people, num_kpts, seed, tag_gain)[0]
+    px = np.clip(np.rint((x * std + mean) * 255.0), 0, 255).astype(np.uint8)
+    return [np.ascontiguousarray(px[i].transpose(1, 2, 0)) for i in range(batch)]

@@ -9,10 +9,14 @@ pkg = importlib.import_module("pytorch-human-pose_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 flip = len(sys.argv) > 2 and sys.argv[2] == "flip"
 net = pkg.HigherHRNet(17, 32)
-net.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()})
+garbage = len(sys.argv) > 3 and sys.argv[3] == "garbage"  # plain random weights: every candidate passes det_thr (decode worst case)
+if garbage:
+    net.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()})
+else:  # pass-through weights: the maps hold the ~10 people encoded in each image
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in pkg.synth.synth_passthrough_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 17, 0, tag_gain=8.0).items()})
 model = pkg.InferenceKeypointsModel(net, det_thr=0.05, tag_thr=0.5, use_flip=flip, input_size=512, device="cuda:0")
 rs = np.random.RandomState(0)
-images = [rs.randint(0, 255, (512, 512, 3)).astype(np.uint8) for _ in range(n)]
+images = [rs.randint(0, 255, (512, 512, 3)).astype(np.uint8) for _ in range(n)] if garbage else pkg.synth.synth_passthrough_raw_u8(64, 128, 128, 10, 17, 0) * (n // 64)
 model.infer_images(images[:64])
 torch.cuda.synchronize(); t0 = time.perf_counter()
 res = model.infer_images(images)
@@ -21,4 +25,5 @@ for im in images[:4]: model(im, None)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for im in images[:32]: model(im, None)
 torch.cuda.synchronize(); t2 = (time.perf_counter() - t0) / 32
+print("people per image (first 8):", [len(r.obj_scores) for r in res[:8]])
 print(f"infer_images: {n / t1:.1f} img/s ({t1 / n * 1e3:.3f} ms/img, flip={flip}); single calls: {1 / t2:.1f} img/s ({t2 * 1e3:.2f} ms/img)")
