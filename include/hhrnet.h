@@ -228,6 +228,15 @@ int hh_bn_train_forward(const void *x, int64_t P, int C, const float *gamma, con
 int hh_bn_train_backward(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd,
                          const float *gamma, int relu, void *dx, void *dres, float *dgamma, float *dbeta, double *scratch, void *stream);
 
+/* FusionLayer's sum in the training step (hrnet.py:214-229: `sum_j f_ij(x_j)` then ReLU, with nn.Upsample(nearest) on the
+ * low-resolution terms, hrnet.py:200-205): out = act(sum_j term_j[b, y >> shift_j, x >> shift_j, :]) over 1..4 NHWC bf16
+ * terms [B, H >> shift_j, W >> shift_j, C] (shift 0 first), summed in fp32 -- the upsampled tensors are never materialised.
+ * Backward: g = dy * (out > 0) [B,H,W,C] is the gradient of every shift-0 term (g may be NULL when relu == 0: then it is dy
+ * itself); dup[j] [B, H >> s, W >> s, C] = the 2^s x 2^s block sums of g for the nup upsampled terms.                     */
+int hh_fusion_sum_forward(const void *const *terms, const int *shifts, int nterms, int B, int H, int W, int C, int relu, void *out, void *stream);
+int hh_fusion_sum_backward(const void *dy, const void *out, int relu, int B, int H, int W, int C, void *g, void *const *dup, const int *up_shift,
+                           int nup, void *stream);
+
 /* SyncBatchNorm (src/base/model.py:42-44: `to_DDP(..., use_batchnorm=True)` converts every BatchNorm2d, the reference
  * trainer's default, trainer.py:44,253; experiments/keypoints/higher_hrnet_32.yaml:17 turns it off): the two passes above split around their one exchange step.
  *   hh_bn_train_stats:          sums[2c], sums[2c+1] = sum x, sum x^2 over THIS rank's P pixels (doubles).

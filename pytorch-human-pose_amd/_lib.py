@@ -78,6 +78,8 @@ def _sig(lib):
         "hh_conv2d": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp]),
         "hh_conv2d_wgrad_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32, i32]),
         "hh_conv2d_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+        "hh_fusion_sum_forward": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+        "hh_fusion_sum_backward": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
         "hh_bn_train_forward": (i32, [vp, i64, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, vp, vp]),
         "hh_bn_train_backward": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
         "hh_conv2d_packed_elems": (i64, [i32, i32, i32, i32, i32]),

@@ -71,7 +71,6 @@ constexpr int MID_BYTES = MT * 32 * PS;      // 50688
 constexpr int W_UNITS = 9 * 4 * C;           // 2304 sixteen-byte units of one 32-input-channel weight chunk
 constexpr int W_BYTES = W_UNITS * 16;        // 36864
 constexpr int NWL = (W_UNITS + NTHR - 1) / NTHR;    // 5 (the last round is half idle)
-constexpr int NCHUNK = C / 32;               // 2 chunks per conv
 }  // namespace
 
 size_t bb64_lds_bytes() { return PATCH_BYTES + MID_BYTES + W_BYTES + 2 * C * 4; }

@@ -371,6 +371,30 @@ int hh_bn_train_backward(const void *x, const void *y, const void *dy, int64_t P
     return 0;
 }
 
+int hh_fusion_sum_forward(const void *const *terms, const int *shifts, int nterms, int B, int H, int W, int C, int relu, void *out, void *stream)
+{
+    if (!terms || !shifts || nterms < 1 || nterms > 4 || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || shifts[0] != 0) { hh_set_error("hh_fusion_sum_forward: 1..4 terms, the first at the output resolution, C a multiple of 8"); return 1; }
+    UpAddParams p{};
+    p.base = (const bf16_raw *)terms[0]; p.base_cs = C;
+    p.nup = nterms - 1;
+    for (int j = 1; j < nterms; ++j) {
+        if (shifts[j] < 0 || shifts[j] > 5 || (H >> shifts[j]) << shifts[j] != H || (W >> shifts[j]) << shifts[j] != W) { hh_set_error("hh_fusion_sum_forward: bad shift"); return 1; }
+        p.up[j - 1] = (const bf16_raw *)terms[j]; p.up_cs[j - 1] = C; p.up_shift[j - 1] = shifts[j];
+    }
+    p.out = (bf16_raw *)out; p.out_cs = C;
+    p.B = B; p.H = H; p.W = W; p.C = C; p.relu = relu;
+    HH_CHECK_HIP(launch_upadd(p, (hipStream_t)stream));
+    return 0;
+}
+int hh_fusion_sum_backward(const void *dy, const void *out, int relu, int B, int H, int W, int C, void *g, void *const *dup, const int *up_shift, int nup,
+                           void *stream)
+{
+    if (!dy || (relu && (!out || !g)) || nup < 0 || nup > 3 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) { hh_set_error("hh_fusion_sum_backward: bad argument"); return 1; }
+    HH_CHECK_HIP(launch_upadd_backward((const bf16_raw *)dy, (const bf16_raw *)out, relu, B, H, W, C, (bf16_raw *)g, (bf16_raw *const *)dup, up_shift, nup,
+                                       (hipStream_t)stream));
+    return 0;
+}
+
 static bool bn_dims_ok(int64_t P, int C) { return P > 0 && C > 0 && C % 8 == 0 && C <= 2048; }
 
 int hh_bn_train_stats(const void *x, int64_t P, int C, double *sums, double *scratch, void *stream)

@@ -183,6 +183,8 @@ struct UpAddParams {
     int B, H, W, C, relu;
 };
 hipError_t launch_upadd(const UpAddParams &p, hipStream_t s);
+hipError_t launch_upadd_backward(const bf16_raw *dy, const bf16_raw *out, int relu, int B, int H, int W, int C, bf16_raw *g, bf16_raw *const *dup,
+                                 const int *up_shift, int nup, hipStream_t s);
 // the same on e4m3 tensors: out = e4m3(act(base * base_scale + sum_j up_j * up_scale[j]) * out_inv_scale); C multiple of 16
 struct UpAddFp8Params {
     const unsigned char *base; int base_cs; float base_scale;

@@ -54,6 +54,59 @@ hipError_t launch_upadd(const UpAddParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- backward of the fusion sum (training): g = dy * (out > 0) at the output resolution (the gradient of every same-resolution
+// term), and for a term that was nearest-upsampled by 2^s the sum of g over its 2^s x 2^s block (fp32 sum, one bf16 rounding).
+__global__ __launch_bounds__(256) void upadd_mask_kernel(const bf16_raw *__restrict__ dy, const bf16_raw *__restrict__ out, bf16_raw *__restrict__ g, size_t n8)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 d = reinterpret_cast<const uint4 *>(dy)[i], o = reinterpret_cast<const uint4 *>(out)[i];
+        auto m = [](unsigned dv, unsigned ov) {  // bf16 pairs: keep dy where out > 0 (out is a ReLU output: > 0 <=> bits != 0 and sign clear)
+            const unsigned lo = ((ov & 0xffffu) != 0u && !(ov & 0x8000u)) ? 0xffffu : 0u, hi_ = ((ov >> 16) != 0u && !(ov & 0x80000000u)) ? 0xffff0000u : 0u;
+            return dv & (lo | hi_);
+        };
+        reinterpret_cast<uint4 *>(g)[i] = make_uint4(m(d.x, o.x), m(d.y, o.y), m(d.z, o.z), m(d.w, o.w));
+    }
+}
+__global__ __launch_bounds__(256) void upadd_blocksum_kernel(const bf16_raw *__restrict__ g, bf16_raw *__restrict__ dup, int B, int h, int w, int C, int sh)
+{
+    const int c8n = C / 8, W = w << sh;
+    const size_t total = (size_t)B * h * w * c8n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        const size_t pix = i / c8n;
+        const int x = (int)(pix % w), y = (int)((pix / w) % h), b = (int)(pix / ((size_t)w * h));
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int dy_ = 0; dy_ < (1 << sh); ++dy_)
+            for (int dx_ = 0; dx_ < (1 << sh); ++dx_) {
+                const size_t src = ((size_t)b * (h << sh) + ((y << sh) + dy_)) * W + ((x << sh) + dx_);
+                const uint4 u = *reinterpret_cast<const uint4 *>(g + src * C + c8 * 8);
+                v[0] += lo(u.x); v[1] += hi(u.x); v[2] += lo(u.y); v[3] += hi(u.y);
+                v[4] += lo(u.z); v[5] += hi(u.z); v[6] += lo(u.w); v[7] += hi(u.w);
+            }
+        *reinterpret_cast<uint4 *>(dup + pix * C + c8 * 8) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    }
+}
+hipError_t launch_upadd_backward(const bf16_raw *dy, const bf16_raw *out, int relu, int B, int H, int W, int C, bf16_raw *g, bf16_raw *const *dup,
+                                 const int *up_shift, int nup, hipStream_t s)
+{
+    const size_t n8 = (size_t)B * H * W * C / 8;
+    const bf16_raw *gsrc = dy;
+    if (relu) {
+        unsigned grid = (unsigned)((n8 + 255) / 256);
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(upadd_mask_kernel, dim3(grid), dim3(256), 0, s, dy, out, g, n8);
+        gsrc = g;
+    }
+    for (int j = 0; j < nup; ++j) {
+        const int sh = up_shift[j], h = H >> sh, w = W >> sh;
+        const size_t total = (size_t)B * h * w * (C / 8);
+        unsigned grid = (unsigned)((total + 255) / 256);
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(upadd_blocksum_kernel, dim3(grid), dim3(256), 0, s, gsrc, dup[j], B, h, w, C, sh);
+    }
+    return hipGetLastError();
+}
+
 // ---- the same fusion sum on e4m3 tensors (fp8 path): every operand carries its tensor scale, the sum is formed in fp32 and
 // requantised with the output scale.  One thread = 16 channels (16 B) of one pixel.
 __device__ __forceinline__ void fp8x16_fma(const uint4 q, float s, float v[16])

@@ -59,6 +59,23 @@ class _BNFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, None, None, None
 
 
+class _FusionSumFn(torch.autograd.Function):
+    """FusionLayer's `relu(sum_j f_ij(x_j))` (hrnet.py:214-229) with the nearest upsample of the low-resolution terms folded into
+    the read (hh_fusion_sum_forward / _backward): no upsampled tensor, no chain of elementwise adds."""
+
+    @staticmethod
+    def forward(ctx, shifts: tuple, *terms: Tensor):
+        out = ops.fusion_sum(list(terms), list(shifts), relu=True)
+        ctx.save_for_backward(out)
+        ctx.shifts = shifts
+        return out
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        (out,) = ctx.saved_tensors
+        return (None, *ops.fusion_sum_backward(dy, out, list(ctx.shifts), relu=True))
+
+
 def _pad_c(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
@@ -210,22 +227,22 @@ def _fusion(xs, fl, n_out):
     outs = []
     for i in range(n_out):
         row = fl.scales_fusion_layers._modules.get(str(i)) if hasattr(fl, "scales_fusion_layers") else None
-        acc = None
+        terms, shifts = [xs[i]], [0]  # the identity term first: it has the output resolution
         for j, x in enumerate(xs):
             if j == i:
-                t = x
+                continue
+            q = row._modules[str(j)]
+            if j > i:  # 1x1 conv + BN at the low resolution; nn.Upsample(nearest) happens inside the sum
+                terms.append(bn(conv(x, q._modules["0"]), q._modules["1"]))
+                shifts.append(j - i)
             else:
-                q = row._modules[str(j)]
-                if j > i:
-                    t = bn(conv(x, q._modules["0"]), q._modules["1"])
-                    t = F.interpolate(t, scale_factor=2 ** (j - i), mode="nearest")
-                else:
-                    t = x
-                    for k in range(i - j):
-                        qq = q._modules[str(k)]
-                        t = bn(conv(t, qq._modules["0"]), qq._modules["1"], relu=(k != i - j - 1))
-            acc = t if acc is None else acc + t
-        outs.append(F.relu(acc))
+                t = x
+                for k in range(i - j):
+                    qq = q._modules[str(k)]
+                    t = bn(conv(t, qq._modules["0"]), qq._modules["1"], relu=(k != i - j - 1))
+                terms.append(t)
+                shifts.append(0)
+        outs.append(_FusionSumFn.apply(tuple(shifts), *terms))
     return outs
 
 
@@ -255,8 +272,7 @@ def higher_hrnet_train_forward(net, images: Tensor):
             last = s == 3 and b == nblocks[s] - 1
             if s > 0:
                 xs = _fusion(xs, st.blocks._modules[str(2 * b + 1)], 1 if last else len(xs))
-            else:
-                xs = [F.relu(xs[0])]
+            # (stage 0 has one scale: its "fusion" is the ReLU of a ReLU output, hrnet.py:221-229 -- the identity, gradient included)
         if s < 3:
             tb = st.transition_layer.transition_blocks
             n = len(xs)

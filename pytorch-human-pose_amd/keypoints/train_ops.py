@@ -212,3 +212,39 @@ def conv2d_weight_grad(x: Tensor, dy: Tensor, ks: int, stride: int = 1, pad: tup
         py_, px_ = pad if pad is not None else (-1, -1)
         _lib.check(lib.hh_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), B, H, W, cin, cout, ks, stride, py_, px_, dw.data_ptr(), ws.data_ptr(), stream))
     return dw
+
+
+def fusion_sum(terms: list[Tensor], shifts: list[int], relu: bool = True) -> Tensor:
+    """out = act(sum_j nearest_upsample(terms[j], 2 ** shifts[j])) (hh_fusion_sum_forward); terms[0] has the output resolution."""
+    import ctypes as C
+    lib = _lib.load()
+    terms = [_nhwc(t) for t in terms]
+    B, Cc, H, W = terms[0].shape
+    out = torch.empty_like(terms[0])
+    ptrs = (C.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+    sh = (C.c_int * len(terms))(*shifts)
+    stream = torch.cuda.current_stream(out.device).cuda_stream
+    with torch.cuda.device(out.device):
+        _lib.check(lib.hh_fusion_sum_forward(ptrs, sh, len(terms), B, H, W, Cc, int(relu), out.data_ptr(), stream))
+    return out
+
+
+def fusion_sum_backward(dy: Tensor, out: Tensor, shifts: list[int], relu: bool = True) -> list[Tensor]:
+    """-> the gradient of every term of fusion_sum (shift-0 terms share one tensor)."""
+    import ctypes as C
+    lib = _lib.load()
+    dy, out = _nhwc(dy), _nhwc(out)
+    B, Cc, H, W = dy.shape
+    g = torch.empty_like(dy) if relu else dy
+    ups = [(j, s) for j, s in enumerate(shifts) if s > 0]
+    dups = [torch.empty((B, Cc, H >> s, W >> s), device=dy.device, dtype=dy.dtype).contiguous(memory_format=torch.channels_last) for _, s in ups]
+    ptrs = (C.c_void_p * max(len(dups), 1))(*[t.data_ptr() for t in dups])
+    sh = (C.c_int * max(len(dups), 1))(*[s for _, s in ups])
+    stream = torch.cuda.current_stream(dy.device).cuda_stream
+    with torch.cuda.device(dy.device):
+        _lib.check(lib.hh_fusion_sum_backward(dy.data_ptr(), out.data_ptr(), int(relu), B, H, W, Cc, g.data_ptr() if relu else None, ptrs, sh,
+                                              len(dups), stream))
+    grads: list = [g] * len(shifts)
+    for (j, _), d in zip(ups, dups):
+        grads[j] = d
+    return grads

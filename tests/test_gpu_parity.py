@@ -524,10 +524,13 @@ def test_training_building_blocks_conv_and_batchnorm(pkg):
     F = torch.nn.functional
     g = torch.Generator().manual_seed(0)
 
-    def close(got, ref, what, tol=1.5e-2):
+    def close(got, ref, what, tol=1.5e-2, min_cos=0.9995):
+        """max error relative to the tensor's max AND direction: cosine with the fp32 reference (a wrong term in a backward
+        formula that stays inside a max-error band still turns the vector: measured cosines are >= 0.99998)."""
         got, ref = got.float().cpu(), ref.float()
         err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
-        assert err < tol, (what, err)
+        cos = float(torch.dot(got.flatten().double(), ref.flatten().double()) / (got.double().norm() * ref.double().norm() + 1e-30))
+        assert err < tol and cos > min_cos, (what, err, cos)
 
     packed_cases = []
     for (cin, cout, ks, stride, hw) in [(64, 64, 3, 1, 32), (32, 32, 3, 1, 40), (128, 64, 1, 1, 16), (64, 256, 1, 1, 24), (64, 128, 3, 2, 32), (32, 32, 3, 2, 24),
@@ -578,6 +581,52 @@ def test_training_building_blocks_conv_and_batchnorm(pkg):
         close(dbeta, beta.grad, ("bn dbeta", C), 2e-2)
         if with_res:
             close(dres, res.grad, ("bn dres", C), 2e-2)
+
+
+def test_fusion_sum_training_op_matches_torch(pkg):
+    """hh_fusion_sum_forward / _backward (FusionLayer's relu(sum of terms) with nn.Upsample(nearest) folded into the read,
+    hrnet.py:200-229) against torch fp32 autograd on the same bf16-rounded operands."""
+    ops = importlib.import_module(PKG + ".keypoints.train_ops")
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(1)
+    for C, H, W, shifts in [(32, 16, 24, [0, 1, 2, 3]), (64, 8, 8, [0, 0, 1]), (128, 4, 8, [0, 0, 0, 1]), (48, 8, 8, [0, 2])]:
+        terms = [_bf(torch.randn(2, C, H >> s, W >> s, generator=g)).requires_grad_() for s in shifts]
+        ref = F.relu(sum(t if s == 0 else F.interpolate(t, scale_factor=2 ** s, mode="nearest") for t, s in zip(terms, shifts)))
+        dev = [t.detach().to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last) for t in terms]
+        out = ops.fusion_sum(dev, shifts, relu=True)
+        assert (out.float().cpu() - ref.detach()).abs().max().item() <= 1.6e-2 * ref.abs().max().item()  # one bf16 rounding of the fp32 sum
+        dy = _bf(torch.randn(2, C, H, W, generator=g))
+        # reference backward with the mask of the kernel's own (bf16) output, as the BatchNorm test does
+        (ref * 0 + sum(t if s == 0 else F.interpolate(t, scale_factor=2 ** s, mode="nearest") for t, s in zip(terms, shifts))
+         ).backward(dy * (out.float().cpu() > 0))
+        grads = ops.fusion_sum_backward(dy.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last), out, shifts, relu=True)
+        for t, gr, s in zip(terms, grads, shifts):
+            a, b = gr.float().cpu(), t.grad
+            assert a.shape == b.shape and (a - b).abs().max().item() <= 8e-3 * max(b.abs().max().item(), 1e-6), (C, s)
+
+
+def test_running_statistics_match_torch_batchnorm(pkg):
+    """The training forward's BatchNorm bookkeeping (train_net.bn + flush_running_stats: the unbiased variance is rebuilt from
+    the kernel's invstd as (1 / invstd^2 - eps) * n / (n - 1)) against nn.BatchNorm2d on the same bf16-rounded input, over
+    three steps with changing inputs: running_mean, running_var, num_batches_tracked."""
+    from torch import nn
+    tn = importlib.import_module(PKG + ".keypoints.train_net")
+    g = torch.Generator().manual_seed(3)
+    for C, hw, B in [(32, 24, 4), (64, 8, 2), (256, 4, 2)]:
+        ours, ref = nn.BatchNorm2d(C).to(DEV), nn.BatchNorm2d(C)
+        with torch.no_grad():
+            for m in (ours, ref):
+                m.weight.copy_(torch.linspace(0.5, 1.5, C)); m.bias.copy_(torch.linspace(-0.2, 0.2, C))
+        ours.train(); ref.train()
+        for step in range(3):
+            x = _bf(torch.randn(B, C, hw, hw, generator=g) * (1 + step) + 0.3 * step)
+            y = tn.bn(x.to(DEV, torch.bfloat16), ours, relu=False)
+            tn.flush_running_stats()
+            yr = ref(x)
+            assert (y.float().cpu() - yr).abs().max().item() < 1.5e-2 * yr.abs().max().item()
+        np.testing.assert_allclose(ours.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ours.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=2e-4, atol=1e-6)
+        assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == 3
 
 
 def test_train_step_matches_reference_autograd(pkg):
