@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round profile recipe (run on the GPU box from the repo root):  bash tools/profile_round.sh r01
+# Round profile recipe (run on the GPU box from the repo root):  bash tools/profile_round.sh r02
 # Four separate rocprofv3 runs of the default bench workload: kernel trace + stats, then one PMC pass each for
 # FETCH_SIZE and WRITE_SIZE (counters are never combined with other trace domains).  Outputs under gpurun_out/<tag>_*;
 # tools/summarise_profile.py turns them into profiles/<tag>_summary.md, <tag>_bench_kernel_stats.csv, traffic_<tag>.json.
@@ -17,3 +17,10 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fet
 echo "fetch pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_write -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > $out/${tag}_write.log 2>&1
 echo "write pass done"
+# fp8 configuration (BASELINE.json configs[4]): serial kernel durations + HBM traffic
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_fp8_serial -- python3 bench.py --config fp8_w48_b64_640 --no-cpu-baseline --single-lane --steps 20 > $out/${tag}_fp8_serial.log 2>&1
+echo "fp8 serial pass done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fp8_fetch -- python3 bench.py --config fp8_w48_b64_640 --no-cpu-baseline --steps 3 --warmup 1 > $out/${tag}_fp8_fetch.log 2>&1
+echo "fp8 fetch pass done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_fp8_write -- python3 bench.py --config fp8_w48_b64_640 --no-cpu-baseline --steps 3 --warmup 1 > $out/${tag}_fp8_write.log 2>&1
+echo "fp8 write pass done"

@@ -102,6 +102,34 @@ for which in ("stats", "serial"):
     for ln in open(os.path.join(out, f"{tag}_{which}.log"), errors="replace"):
         if ln.startswith('{"metric"'):
             lines += ["", f"bench.py line of the traced `{which}` run (profiler attached, so slower than an untraced run):", "", "```", ln.strip(), "```"]
+# fp8 configuration (BASELINE.json configs[4]): serial kernel-trace pass + FETCH/WRITE passes of bench.py --config fp8_w48_b64_640
+fp8_serial = sorted(glob.glob(os.path.join(out, f"{tag}_fp8_serial/**/*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+fp8_traffic = {}
+if fp8_serial:
+    rows = list(csv.DictReader(open(fp8_serial[-1])))
+    try:
+        ffetch, fwrite = pmc("fp8_fetch", "FETCH_SIZE"), pmc("fp8_write", "WRITE_SIZE")
+    except SystemExit:
+        ffetch, fwrite = {}, {}
+    with open(os.path.join(prof, f"{tag}_fp8_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "SerialAverageNs", "SerialPercentage", "hbm_read_bytes_per_launch(2xFETCH_SIZE)", "hbm_write_bytes_per_launch"])
+        for r in rows:
+            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], round(2 * ffetch.get(r["Name"], 0.0)), round(fwrite.get(r["Name"], 0.0))])
+    lines += ["", "## fp8 configuration (`bench.py --config fp8_w48_b64_640 --single-lane`: HigherHRNet-W48, batch 64 @ 640x640, e4m3 MFMA conv path)", "",
+              f"Serial kernel-trace pass (one kernel at a time), full table {tag}_fp8_kernel_stats.csv:", "",
+              "| kernel | calls | avg us (serial) | % time | HBM read MB/launch | HBM write MB/launch |", "|---|---|---|---|---|---|"]
+    for r in rows[:14]:
+        n = r["Name"]
+        lines.append(f"| `{short(n)}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | {2 * ffetch.get(n, 0.0) / 1e6:.1f} | {fwrite.get(n, 0.0) / 1e6:.1f} |")
+    for ln in open(os.path.join(out, f"{tag}_fp8_serial.log"), errors="replace"):
+        if ln.startswith('{"metric"'):
+            lines += ["", "bench.py line of that traced run:", "", "```", ln.strip(), "```"]
+    for n in set(ffetch) | set(fwrite):
+        m = re.search(r"conv_fp8_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", n)
+        if m:
+            ks, s_, kc, nt, pt, tw = m.groups()
+            fp8_traffic[f"conv_fp8_kernel<KS={ks},S={s_},KC={kc},NT={nt},WC=1,PT={pt},TW={tw}>"] = round(2 * ffetch.get(n, 0.0) + fwrite.get(n, 0.0), -5)
 train_csv = os.path.join(prof, f"{tag}_train_step_kernel_stats.csv")
 if os.path.exists(train_csv):  # kept from `rocprofv3 --kernel-trace --stats -- python3 tools/train_bench.py 32 5` (7 steps traced)
     trows = list(csv.DictReader(open(train_csv)))
@@ -128,7 +156,10 @@ for n in set(fetch) | set(write):
         traffic[key] = max(traffic.get(key, 0.0), round(total, -5))
     elif n.startswith("bb_fused_kernel"):
         traffic["bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)"] = round(total, -5)
+    elif n.startswith("bb64_fused_kernel"):
+        traffic["bb64_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=64)"] = round(total, -5)
 DECODE = ("stage_average", "nms_tile_topk", "topk_merge", "match_kernel", "adjust_scores", "refine_", "tag_bounds")
+traffic.update(fp8_traffic)
 traffic["hh_decode (all kernels of one call)"] = round(sum(2 * fetch.get(n, 0.0) + write.get(n, 0.0) for n in set(fetch) | set(write)
                                                            if n.startswith(DECODE)), -5)
 json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --no-cpu-baseline --steps 3 --warmup 1` "
