@@ -148,6 +148,12 @@ int hh_flip_merge(float *hm, int64_t hm_bstride, const float *hm_flipped, int64_
 hh_decoder *hh_decoder_create(int num_kpts, int max_people, double det_thr, double tag_thr);
 void hh_decoder_destroy(hh_decoder *dec);
 int hh_decoder_reserve(hh_decoder *dec, int B, int H, int W, int E); /* H, W = full (model-input) resolution */
+/* By default hh_decode skips the NMS / top-k work of every 60x60 tile whose half-resolution source values cannot exceed
+ * det_thr: such a tile cannot contribute a candidate that survives match_by_tag's `score > det_thr` filter
+ * (grouping.py:98-102), so joints / scores / num_people are unchanged, bit for bit; the no-group fallback's top-1 candidates
+ * are then recomputed from the maps for the flagged images.  What changes is the candidate list itself (sub-threshold
+ * entries are missing): enable = 1 processes every tile, which hh_decoder_read_topk (the reference's full top_k) needs.   */
+int hh_decoder_set_exact_topk(hh_decoder *dec, int enable);
 
 /* InferenceKeypointsResult.from_preds aggregation + MPPEHeatmapParser.parse, batched:
  * keypoints/results.py:225-238 + keypoints/grouping.py:252-283.

@@ -69,6 +69,7 @@ def _sig(lib):
         "hh_decoder_create": (vp, [i32, i32, dbl, dbl]),
         "hh_decoder_destroy": (None, [vp]),
         "hh_decoder_reserve": (i32, [vp, i32, i32, i32, i32]),
+        "hh_decoder_set_exact_topk": (i32, [vp, i32]),
         "hh_decode": (i32, [vp, vp, i64, vp, i64, vp, pi64, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
         "hh_parse": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
         "hh_debug_check_plan": (i32, [vp]),

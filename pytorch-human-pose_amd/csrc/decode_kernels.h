@@ -31,8 +31,11 @@ struct DecodeSrc {
 hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, int B,
                                 int K, int hq, int wq, hipStream_t s);
 // per (b,k,tile): top-M candidates of the NMS'ed map as sortable keys + exact values
+// skip_thr: tiles whose values cannot exceed it emit no candidates (-INFINITY: every tile is processed, the exact top-k)
 hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, unsigned long long *cand_key, float *cand_val, float *cellmax,
-                                hipStream_t s);
+                                float skip_thr, hipStream_t s);
+// images flagged HH_DECODE_FALLBACK: joints[b, 0, k] = the top-1 candidate of joint k recomputed from the map
+hipError_t launch_fallback_top1(const DecodeSrc &src, int M, const int32_t *flags, float *joints, hipStream_t s);
 // per (b,k): merge the tiles' candidates -> scores_k, coords_k (x,y), tags_k
 hipError_t launch_topk_merge(const DecodeSrc &src, int M, int ntiles, unsigned long long *cand_key, const float *cand_val,
                              float *tags_k, int32_t *coords_k, float *scores_k, hipStream_t s);

@@ -127,7 +127,7 @@ __device__ long long g_nms_dbg[4096 * 8];
 #endif
 
 __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src, int M, int tiles_x, int ntile, u64 *__restrict__ cand_key,
-                                                            float *__restrict__ cand_val, float *__restrict__ cellmax)
+                                                            float *__restrict__ cand_val, float *__restrict__ cellmax, float skip_thr)
 {
     // Geometry: a 60x60 tile has a 64x64 halo'ed neighbourhood, so in every pass a wave's 64 lanes are 64 columns (or 64
     // rows x 4 strips are the 256 threads) with nobody idle.
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     __shared__ u64 wbest[2][4];
     __shared__ u64 clist[256];
     __shared__ int ccount, nfilled, need_rows;
+    __shared__ float smax[4];
     float (*hrow)[HS] = reinterpret_cast<float (*)[HS]>(&rm[0][0]);        // [PR][HS] horizontally interpolated half-res rows
     float (*patch)[PR + 1] = reinterpret_cast<float (*)[PR + 1]>(&rm[0][0]);  // [PR][PR+1] half-res patch (generic scales)
     static_assert(sizeof(float) * PR * HS <= sizeof(rm) && sizeof(float) * PR * (PR + 1) <= sizeof(rm), "aliases fit");
@@ -175,11 +176,41 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             const float *row = img + (size_t)min(py0 + min(wv + 4 * t, PR - 1), hh - 1) * wh;
             ga[t] = row[ca]; gb[t] = row[cb];
         }
+        float tmax = -INFINITY;  // the largest half-res value any pixel of the tile or its halo interpolates
 #pragma unroll
-        for (int t = 0; t < NR; ++t)
+        for (int t = 0; t < NR; ++t) {
             if (wv + 4 * t < PR) hrow[wv + 4 * t][lane] = __builtin_fmaf(ga[t], wxa, gb[t] * wxb);
+            tmax = fmaxf(tmax, fmaxf(ga[t], gb[t]));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
+        if (lane == 0) smax[wv] = tmax;
         lds_barrier();
         NMS_STAMP(1);
+        tmax = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        if (tmax + 4e-7f * fabsf(tmax) <= skip_thr) {
+            // Inactive tile: every full-resolution value in it is a convex combination of half-res values <= tmax (plus a few
+            // ulps of rounding, covered by the slack), so no pixel can pass det_thr and nothing this tile could emit survives
+            // match_by_tag's score filter (grouping.py:98-102).  It emits no candidates; the refine kernel still gets an upper
+            // bound of every 4x4 cell: the maximum of the horizontally interpolated rows the cell's pixels are built from.
+            if (tid < M) cand_key[((((size_t)b * src.K + k) * ntile) + tile) * M + tid] = 0ull;
+            if (tid < (TS / 4) * (TS / 4)) {
+                const int cy = tid / (TS / 4), cx = tid % (TS / 4);
+                const int Y = y0 + 4 * cy, X = x0 + 4 * cx;
+                if (Y < src.H && X < src.W) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int rr = min(max(pry + 2 * cy + a, 0), PR - 1);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) m = fmaxf(m, hrow[rr][2 + 4 * cx + c]);
+                    }
+                    reinterpret_cast<unsigned short *>(cellmax)[(((size_t)b * src.K + k) * (src.H >> 2) + (Y >> 2)) * (src.W >> 2) + (X >> 2)] =
+                        bf16_ceil(m + 4e-7f * fabsf(m));
+                }
+            }
+            return;
+        }
         const bool xin = X >= 0 && X < src.W;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -396,11 +427,59 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     }
 }
 
-hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, u64 *cand_key, float *cand_val, float *cellmax, hipStream_t s)
+hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, u64 *cand_key, float *cand_val, float *cellmax, float skip_thr, hipStream_t s)
 {
     const int tiles_x = (src.W + HH_NMS_TILE - 1) / HH_NMS_TILE, tiles_y = (src.H + HH_NMS_TILE - 1) / HH_NMS_TILE;
     hipLaunchKernelGGL(nms_tile_topk_kernel, dim3(tiles_x * tiles_y * src.K * src.B), dim3(256), 0, s, src, M, tiles_x,
-                       tiles_x * tiles_y, cand_key, cand_val, cellmax);
+                       tiles_x * tiles_y, cand_key, cand_val, cellmax, skip_thr);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ the no-group fallback when tiles were skipped
+// grouping.py:262-269 takes the best candidate of every joint (top_k's first entry) when no group formed.  With sub-threshold
+// tiles skipped that entry may be missing, so for the (rare) flagged images it is recomputed here from the map itself: the
+// first entry of torch.topk over hm * (maxpool5x5(hm) == hm) is the global maximum if that is positive (first index among
+// equals: the tie rule of this implementation), else the first pixel in index order whose NMS'ed value is zero (any pixel that
+// is not a negative peak).
+__global__ __launch_bounds__(256) void fallback_top1_kernel(const DecodeSrc src, int M, const int32_t *__restrict__ flags, float *__restrict__ joints)
+{
+    __shared__ u64 wbest[4];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, D = 3 + src.E;
+    if (!(flags[b] & HH_DECODE_FALLBACK)) return;
+    u64 best = 0ull;
+    for (int y = 0; y < src.H; ++y)
+        for (int x = tid; x < src.W; x += 256) {
+            const u64 key = make_key(heat_at(src, b, k, y, x), (unsigned)(y * src.W + x));
+            best = key > best ? key : best;
+        }
+    best = wave_max_u64(best);
+    if ((tid & 63) == 0) wbest[tid >> 6] = best;
+    __syncthreads();
+    if (tid != 0) return;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) best = wbest[w] > best ? wbest[w] : best;
+    unsigned idx = 0xffffffffu - (unsigned)(best & 0xffffffffull);
+    int x = (int)(idx % (unsigned)src.W), y = (int)(idx / (unsigned)src.W);
+    if (!(heat_at(src, b, k, y, x) > 0.f)) {  // no positive value: zeros of the NMS'ed map come first, in index order
+        for (unsigned i = 0; i < (unsigned)(src.H * src.W); ++i) {
+            const int py = (int)(i / (unsigned)src.W), px = (int)(i % (unsigned)src.W);
+            const float c = heat_at(src, b, k, py, px);
+            float m = c;
+            for (int dy = -2; dy <= 2; ++dy)
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int yy = py + dy, xx = px + dx;
+                    if (yy >= 0 && yy < src.H && xx >= 0 && xx < src.W) m = fmaxf(m, heat_at(src, b, k, yy, xx));
+                }
+            if (!(m == c) || c == 0.f) { x = px; y = py; break; }  // not a peak (NMS'ed to 0) or a zero-valued peak
+        }
+    }
+    float *jr = joints + ((size_t)b * M * src.K + k) * D;
+    jr[0] = (float)x; jr[1] = (float)y; jr[2] = 0.01f;
+    for (int e = 0; e < src.E; ++e) { const float t = tag_at(src, b, k, y, x, e); jr[3 + e] = (t != t) ? 0.f : t; }
+}
+hipError_t launch_fallback_top1(const DecodeSrc &src, int M, const int32_t *flags, float *joints, hipStream_t s)
+{
+    hipLaunchKernelGGL(fallback_top1_kernel, dim3(src.K, src.B), dim3(256), 0, s, src, M, flags, joints);
     return hipGetLastError();
 }
 

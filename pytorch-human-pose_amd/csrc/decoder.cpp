@@ -1,4 +1,5 @@
 // Host side of the decode path: workspace + launch sequence behind hh_decode / hh_parse.
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -16,6 +17,8 @@ struct hh_decoder {
     int32_t *coords_k = nullptr, *flags = nullptr, *ws_jobs = nullptr;  // flags [rB]: HH_DECODE_* bits of the last call
     std::vector<void *> allocs;
     int lastB = 0, lastE = 0;
+    int exact_topk = 0;   // 1: every tile is processed, so hh_decoder_read_topk returns the reference's full top_k
+    int last_exact = 0;
     const int32_t *flags_last = nullptr;
     void release()
     {
@@ -67,10 +70,18 @@ int hh_decoder::run(DecodeSrc &src, int adjust, int refine, float *joints, float
     src.scale_h2 = (float)(src.H / 2) / (float)src.H; src.scale_w2 = (float)(src.W / 2) / (float)src.W;
     src.scale_h4 = (float)(src.H / 4) / (float)src.H; src.scale_w4 = (float)(src.W / 4) / (float)src.W;
     const int nt = ntiles_of(src.H, src.W);
-    HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, cellmax, s));
+    // Tiles that cannot hold a pixel above det_thr are skipped (only for det_thr >= 0: the empty candidate slots read as score 0,
+    // which must fail `score > det_thr`); mode 1 / other scales always run every tile.
+    const bool skip = !exact_topk && det_thr >= 0.0 && src.mode == 0;
+    // the largest float <= det_thr: `bound <= skip_thr` then implies `(double)score <= det_thr` for every pixel of the tile
+    float thr_f = (float)det_thr;
+    if ((double)thr_f > det_thr) thr_f = nextafterf(thr_f, -INFINITY);
+    HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, cellmax, skip ? thr_f : -INFINITY, s));
+    last_exact = !skip;
     HH_CHECK_HIP(launch_topk_merge(src, M, nt, cand_key, cand_val, tags_k, coords_k, scores_k, s));
     HH_CHECK_HIP(launch_match(tags_k, coords_k, scores_k, src.B, K, M, src.E, det_thr, tag_thr, joints, num_people, ws_tags, flags_out ? flags_out : flags, s));
     flags_last = flags_out ? flags_out : flags;
+    if (skip) HH_CHECK_HIP(launch_fallback_top1(src, M, flags_last, joints, s));
     HH_CHECK_HIP(launch_adjust_scores(src, M, adjust, joints, num_people, scores, s));
     if (refine) HH_CHECK_HIP(launch_refine(src, M, joints, num_people, ws_prev, ws_best, ws_jobs, cellmax, tagb, s));
     lastB = src.B; lastE = src.E;
@@ -96,6 +107,7 @@ void hh_decoder_destroy(hh_decoder *dec)
     delete dec;
 }
 int hh_decoder_reserve(hh_decoder *dec, int B, int H, int W, int E) { return dec->reserve(B, H, W, E); }
+int hh_decoder_set_exact_topk(hh_decoder *dec, int enable) { dec->exact_topk = enable != 0; return 0; }
 
 int hh_decode(hh_decoder *dec, const float *hm_q, int64_t hm_q_bstride, const float *hm_h, int64_t hm_h_bstride,
               const float *const *tags_q, const int64_t *tags_bstride, int E, int B, int hq, int wq, int adjust, int refine,
@@ -135,6 +147,7 @@ int hh_resize_accumulate(const float *src, int64_t src_bstride, int B, int K, in
 int hh_decoder_read_topk(hh_decoder *dec, float *tags_k, int32_t *coords_k, float *scores_k)
 {
     if (!dec->lastB) { hh_set_error("hh_decoder_read_topk: nothing decoded yet"); return 1; }
+    if (!dec->last_exact) { hh_set_error("hh_decoder_read_topk: the last call skipped sub-threshold tiles; hh_decoder_set_exact_topk(dec, 1) first"); return 1; }
     HH_CHECK_HIP(hipDeviceSynchronize());
     const size_t n = (size_t)dec->lastB * dec->K * dec->M;
     HH_CHECK_HIP(hipMemcpy(tags_k, dec->tags_k, n * dec->lastE * 4, hipMemcpyDeviceToHost));

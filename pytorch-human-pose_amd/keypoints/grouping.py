@@ -43,6 +43,11 @@ class MPPEHeatmapParser:
         self._handle = _DecHandle(self._lib, num_kpts, max_num_people, det_thr, tag_thr)
         self._h = self._handle.ptr
 
+    def set_exact_topk(self, enable: bool) -> None:
+        """hh_decoder_set_exact_topk: True = every NMS tile is processed, so `last_top_k` / `top_k` return the reference's full
+        candidate lists; False (default) = tiles that cannot reach det_thr are skipped (same parse results, faster)."""
+        self._lib.hh_decoder_set_exact_topk(self._h, int(enable))
+
     # ------------------------------------------------------------------ device-side batch API
     def _outputs(self, B: int, E: int, device):
         K, M = self.num_kpts, self.max_num_people
@@ -134,6 +139,10 @@ class MPPEHeatmapParser:
         """grouping.py:147-170 -> (tags_k [K,M,E], coords_k [K,M,2] int32 (x,y), scores_k [K,M])"""
         if tags_hms.dim() == 3:
             tags_hms = tags_hms[..., None]
-        self.parse_batch_device(kpts_hms[None], tags_hms[None], False, False)
-        t, c, s = self.last_top_k(1, tags_hms.shape[-1])
+        self.set_exact_topk(True)
+        try:
+            self.parse_batch_device(kpts_hms[None], tags_hms[None], False, False)
+            t, c, s = self.last_top_k(1, tags_hms.shape[-1])
+        finally:
+            self.set_exact_topk(False)
         return t[0], c[0], s[0]

@@ -122,7 +122,14 @@ def test_decode_bit_exact_vs_reference_golden(pkg, synth, decode_golden):
             assert j.dtype == rj.dtype and j.shape == rj.shape and np.array_equal(j, rj), (tag, name)
             if name == "joints":
                 assert s.dtype == rs.dtype and np.array_equal(s, rs), tag
+        # the candidate lists themselves need every tile (the default skips tiles that cannot reach det_thr: same parse results)
+        outd = [x.clone() for x in parser.decode_batch_device(t(hm_q), t(hm_h), [t(x) for x in tags])]
+        parser.set_exact_topk(True)
+        oute = parser.decode_batch_device(t(hm_q), t(hm_h), [t(x) for x in tags])
+        n0 = int(outd[2][0])
+        assert int(oute[2][0]) == n0 and torch.equal(outd[0][0, :n0], oute[0][0, :n0]) and torch.equal(outd[1][0, :n0], oute[1][0, :n0]) and torch.equal(outd[3], oute[3]), tag
         tk, ck, sk = parser.last_top_k(1, m["emb"])
+        parser.set_exact_topk(False)
         full, tfull = orc.aggregate(hm_q, hm_h, tags)
         otk, ock, osk = orc.top_k(full, tfull, m["max_people"])
         assert np.array_equal(sk[0], osk) and np.array_equal(ck[0], ock) and np.array_equal(tk[0], otk), tag
@@ -494,7 +501,11 @@ def test_full_size_properties_batch32_512(pkg):
     parser = pkg.MPPEHeatmapParser(K, 30, 0.05, 0.5)
     joints, scores, num, flags = [t.clone() for t in parser.decode_batch_device(hm_q, hm_h, [tags])]
     assert not flags.any()
+    parser.set_exact_topk(True)   # every tile processed: identical results, and the full candidate lists are available
+    exact = parser.decode_batch_device(hm_q, hm_h, [tags])
+    assert all(torch.equal(a, b) for a, b in zip((joints, scores, num, flags), exact))
     _, _, sk = parser.last_top_k(B, 1)
+    parser.set_exact_topk(False)
     assert np.all(np.diff(sk, axis=-1) <= 0)  # per joint: candidates in descending score order
     n = num.cpu().numpy()
     assert n.min() >= 1 and n.max() <= 30
