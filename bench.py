@@ -362,6 +362,7 @@ def main():
             d = per_cfg[dom]
             cfgv = (C.c_int * 7)()
             kname = {100: "bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)",
+                     104: "bb128_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=128)",
                      103: "bb64_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=64)",
                      102: "stem_conv_kernel (fp32 NCHW -> conv3x3 s2 3->64 + BN + ReLU -> bf16 NHWC)",
                      101: "junction_kernel (stage-0 conv3 1x1 [+downsample] + residual + ReLU + next conv1 1x1 + ReLU)"}.get(dom, str(dom))

@@ -196,15 +196,24 @@ struct Builder {
         return conv(L(p + "." + c, p + "." + b, cin, cout, ks, stride), in, out, relu, res);
     }
     // four BasicBlocks "<prefix>.<u>" on tensor x with scratch m (both C channels); result ends in x
-    void basic_blocks(const std::string &prefix, int C, int x, int m)
+    // `nscales` = number of resolution branches running beside this one (0: no siblings, e.g. the deconv head)
+    void basic_blocks(const std::string &prefix, int C, int x, int m, int nscales = 0)
     {
+        // The fused 128-channel block (basicblock_fused_c128.hip: 25.7 us per block against 2 x 18.4 us layer by layer when the
+        // kernels run one at a time) is OFF by default: with the branch lanes running side by side it loses -- one box, two
+        // alternations: 5512 / 5511 img/s without it, 5451 / 5432 with it in stage 2 only, 5395 / 5415 everywhere.  Its 150 KB
+        // workgroups take whole CUs, while the layer-by-layer launches (64 KB workgroups) share CUs with each other and with
+        // the 256-channel branch.  HH_BB128=all | stage2 enables it (serial execution, experiments).
+        const char *e128 = getenv("HH_BB128");
+        const bool bb128 = C == 128 && e128 && (!strcmp(e128, "all") || (!strcmp(e128, "stage2") && nscales == 3));
         for (int u = 0; u < 4; ++u) {
             const std::string up = prefix + "." + std::to_string(u);
-            if ((C == 32 || (C == 64 && !getenv("HH_NO_BB64"))) && n.dtype != 2) {  // fused kernels, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
+            if ((C == 32 || (C == 64 && !getenv("HH_NO_BB64")) || bb128) && n.dtype != 2) {  // fused kernels, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
                 Op o;
                 o.kind = OP_BB;
                 o.layer = L(up + ".conv1", up + ".bn1", C, C, 3, 1);
                 o.layer2 = L(up + ".conv2", up + ".bn2", C, C, 3, 1);
+                n.layers[o.layer].bb128 = n.layers[o.layer2].bb128 = (C == 128);
                 o.in = (u & 1) ? m : x;
                 o.out = (u & 1) ? x : m;
                 o.lane = lane;
@@ -295,7 +304,7 @@ struct Builder {
                 const std::string hp = sp + ".blocks." + std::to_string(2 * b);
                 for (int i = 0; i < nsc; ++i) {  // branches are independent (hrnet.py:154-163): one lane each
                     lane = i;
-                    basic_blocks(hp + ".scales_blocks." + std::to_string(i), w[i], x[i], m[i]);
+                    basic_blocks(hp + ".scales_blocks." + std::to_string(i), w[i], x[i], m[i], nsc);
                 }
                 lane = 0;
                 join(nsc);  // every fusion output reads every branch
@@ -464,6 +473,7 @@ int hh_net::finalize()
     HH_CHECK_HIP(conv_init());
     HH_CHECK_HIP(bb_fused_init());
     HH_CHECK_HIP(bb64_fused_init());
+    HH_CHECK_HIP(bb128_fused_init());
     HH_CHECK_HIP(junction_init());
     if (dtype == 2 && kind != 0) { hh_set_error("hh_finalize: the fp8 path covers HigherHRNet only"); return 1; }
     {
@@ -499,7 +509,8 @@ int hh_net::finalize()
         }
         if (dtype == 2) continue;  // e4m3 weights: finalize_fp8() below
         const int cin_pad0 = round_up(l.cin, 16), coutp = round_up(l.cout, 32);
-        if (hh_family_pick(l.ks, l.stride, cin_pad0, coutp, &l.KC, &l.NT)) {
+        if (l.bb128) { l.KC = 16; l.NT = 4; }  // basicblock_fused_c128.hip: [chunk of 16 cin][tap][2][128 couts][8]
+        else if (hh_family_pick(l.ks, l.stride, cin_pad0, coutp, &l.KC, &l.NT)) {
             hh_set_error("no kernel family for conv " + l.conv);
             return 1;
         }
@@ -811,14 +822,15 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr = &prof[prof_used++];
                 pr->op = (int)(&op - ops.data());
                 const double Cb = l1.cout;
-                pr->cfg = l1.cout == 64 ? HH_CFG_BB64_FUSED : HH_CFG_BB_FUSED;
+                pr->cfg = l1.cout == 128 ? HH_CFG_BB128_FUSED : l1.cout == 64 ? HH_CFG_BB64_FUSED : HH_CFG_BB_FUSED;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
                 if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 2 * pr->slot;
                 pr->flops = 2.0 * 2.0 * B * p.H * p.W * Cb * Cb * 9.0;
                 pr->bytes = 2.0 * B * p.H * p.W * Cb * 2 + 2.0 * 2 * 9 * Cb * Cb;
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
             }
-            if (l1.cout == 64) HH_CHECK_HIP(bb64_fused_launch(p, num_cus, s));
+            if (l1.cout == 128) HH_CHECK_HIP(bb128_fused_launch(p, num_cus, s));
+            else if (l1.cout == 64) HH_CHECK_HIP(bb64_fused_launch(p, num_cus, s));
             else HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
             break;
         }

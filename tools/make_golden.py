@@ -344,8 +344,48 @@ def train_fixture():
     print("train fixture: loss", out["loss"], "params", len(names))
 
 
+def train_autocast_fixture():
+    """The same step at the REFERENCE'S training precision (keypoints/module.py:48-60: forward under
+    torch.autocast(dtype=float16), backward through a GradScaler): CPU autocast runs the reference net with fp16 conv operands
+    / fp16 activations here.  The loss scale is what GradScaler's halving converges to from its initial 65536: the largest
+    power of two that leaves every gradient finite.  Stored like train_step.npz (same sample indices), so that the bf16 engine's
+    deviation from the fp32 step can be put beside the reference's own mixed-precision deviation."""
+    x = torch.from_numpy(synth.synth_images(2, 128, 128, seed=1))
+    scale = 65536.0
+    while True:
+        net = HigherHRNet(17, 32)
+        load_synth(net, 5)
+        net.train()
+        with torch.autocast(device_type="cpu", dtype=torch.float16):
+            hms, tags = net(x)
+            loss = (hms[0].float() ** 2).mean() + (hms[1].float() ** 2).mean() + (tags.float() ** 2).mean()
+        (loss * scale).backward()
+        if all(torch.isfinite(p.grad).all() for p in net.parameters()):
+            break
+        scale /= 2  # GradScaler: skip the step, halve the scale
+    out = {"loss": np.float32(loss.item()), "loss_scale": np.float64(scale)}
+    rs = np.random.RandomState(3)
+    for name, t in (("hm0", hms[0]), ("hm1", hms[1]), ("tags", tags)):
+        a = t.detach().float().numpy().ravel()
+        idx = rs.randint(0, a.size, 256)
+        out[f"{name}.idx"], out[f"{name}.val"] = idx.astype(np.int64), a[idx]
+    names, norms, samples = [], [], []
+    for name, p in net.named_parameters():
+        g = (p.grad / scale).numpy().ravel()
+        names.append(name)
+        norms.append(np.linalg.norm(g.astype(np.float64)))
+        samples.append(g[np.linspace(0, g.size - 1, 4).astype(int)])
+    out["grad.names"] = np.array(names)
+    out["grad.norms"] = np.array(norms, np.float64)
+    out["grad.samples"] = np.stack(samples).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "train_step_autocast.npz"), **out)
+    print("autocast train fixture: loss", out["loss"], "scale", scale)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "decode", "flip", "munkres", "geometry", "loss", "train"]
+    which = sys.argv[1:] or ["net", "decode", "flip", "munkres", "geometry", "loss", "train", "train_autocast"]
+    if "train_autocast" in which:
+        train_autocast_fixture()
     if "train" in which:
         train_fixture()
     if "loss" in which:
