@@ -131,6 +131,30 @@ class KeypointsModule:
             metrics[f"pull_{i}_loss"] = pull_losses[i].item()
         return metrics
 
+    def validation_step(self, batch, batch_idx: int = 0):
+        """`KeypointsModule.validation_step` (keypoints/module.py:73-111): forward, the same losses as the training step (no
+        backward), and one KeypointsResult per image decoded at the validation thresholds (20 people, det 0.1, tag 1.0).  The
+        reference decodes image by image on the host; here the whole batch goes through one hh_decode."""
+        from .results import KeypointsResult
+        images, heatmaps, masks, joints = batch
+        with torch.no_grad():
+            stages_hms, tags = self.model.net(images)
+            hm_losses, push_losses, pull_losses = self.loss_fn.calculate_loss(stages_hms, tags, heatmaps, masks, joints)
+        loss = hm_losses[0] + hm_losses[1] + push_losses[0] + pull_losses[0]
+        metrics = {"loss": loss.detach().item()}
+        for i, hl in enumerate(hm_losses):
+            metrics[f"hm_{i}_loss"] = hl.item()
+        for i in range(len(push_losses)):
+            metrics[f"push_{i}_loss"] = push_losses[i].item()
+            metrics[f"pull_{i}_loss"] = pull_losses[i].item()
+        stages_hms, tags = [h.detach().float() for h in stages_hms], tags.detach().float()
+        parser = MPPEHeatmapParser(stages_hms[0].shape[1], 20, 0.1, 1.0)
+        cpu_images = images.detach().cpu()
+        results = [KeypointsResult(cpu_images[i], [h[i:i + 1] for h in stages_hms], tags[i:i + 1], COCO_LIMBS, 20, 0.1, 1.0, parser=parser)
+                   for i in range(len(cpu_images))]
+        KeypointsResult.set_preds_batch(results, stages_hms, tags)
+        return metrics, results
+
 
 class InferenceKeypointsModel:
     limbs = COCO_LIMBS

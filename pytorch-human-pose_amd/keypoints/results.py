@@ -27,6 +27,40 @@ def transform_coords(kpts_coords: np.ndarray, center, scale, output_size) -> np.
     return out.reshape(kpts_coords.shape).astype(kpts_coords.dtype)
 
 
+class KeypointsResult:
+    """Validation-time result of one image (`results.py:70-124`, without the plotting helpers): the stage heatmaps and tags of
+    the net as they come out of `forward` (batch dim kept: [1,K,h,w]), decoded on demand by `set_preds()` with this result's
+    own thresholds (validation uses max_num_people=20, det_thr=0.1, tag_thr=1.0, `keypoints/module.py:100-108`).  Coordinates
+    are model-input pixels (no un-warp: the validation image IS the model input)."""
+
+    def __init__(self, model_input_image: Tensor, kpts_heatmaps: list[Tensor], tags_heatmaps: Tensor, limbs, max_num_people: int = 30,
+                 det_thr: float = 0.05, tag_thr: float = 0.5, parser: MPPEHeatmapParser | None = None):
+        self.model_input_image = model_input_image
+        self._kpts_heatmaps = kpts_heatmaps
+        self._tags_heatmaps = tags_heatmaps
+        self.num_kpts = kpts_heatmaps[0].shape[1]
+        self.limbs = limbs
+        self.max_num_people, self.det_thr, self.tag_thr = max_num_people, det_thr, tag_thr
+        self.hm_parser = parser or MPPEHeatmapParser(self.num_kpts, max_num_people, det_thr, tag_thr)
+
+    def _assign(self, joints: np.ndarray, scores: np.ndarray) -> None:
+        self.kpts_coords, self.kpts_scores, self.kpts_tags, self.obj_scores = joints[..., :2], joints[..., 2], joints[..., 3:], scores
+
+    def set_preds(self) -> None:
+        """results.py:94-124: stage average, resize, parse -- fused in hh_decode."""
+        out = self.hm_parser.decode_batch_device(self._kpts_heatmaps[0], self._kpts_heatmaps[1], [self._tags_heatmaps], adjust=True, refine=True)
+        self._assign(*self.hm_parser.to_lists(*out)[0])
+
+    @staticmethod
+    def set_preds_batch(results: list["KeypointsResult"], stages: list[Tensor], tags: Tensor) -> None:
+        """The same for every image of a batch in ONE hh_decode call (identical per-image results: images are independent)."""
+        if not results:
+            return
+        parser = results[0].hm_parser
+        for r, (j, s) in zip(results, parser.to_lists(*parser.decode_batch_device(stages[0], stages[1], [tags], adjust=True, refine=True))):
+            r._assign(j, s)
+
+
 @dataclass
 class InferenceKeypointsResult:
     raw_image: np.ndarray | None

@@ -449,6 +449,31 @@ def test_chained_forward_decode_on_person_like_maps(pkg):
         assert np.array_equal(got[b][0], oj) and np.array_equal(got[b][1], os_)
 
 
+def test_validation_step_decodes_at_the_validation_thresholds(pkg):
+    """KeypointsModule.validation_step (keypoints/module.py:73-111): losses without a backward + one KeypointsResult per image
+    decoded with max_num_people=20, det_thr=0.1, tag_thr=1.0; the batched decode equals per-image set_preds() and the oracle."""
+    net, _ = _passthrough_net(pkg)
+    kp = importlib.import_module(PKG + ".keypoints")
+    res_mod = importlib.import_module(PKG + ".keypoints.results")
+    B, S = 3, 128
+    imgs = pkg.synth.synth_passthrough_images(B, S // 4, S // 4, [2, 4, 0], 17, 5)[0]
+    hms, masks, joints = pkg.synth.synth_train_targets(B, 17, S, 3, seed=2)
+    batch = (torch.from_numpy(imgs).to(DEV), [torch.from_numpy(h).to(DEV) for h in hms], [torch.from_numpy(m).to(DEV) for m in masks], joints)
+    module = kp.KeypointsModule(kp.KeypointsModel(net), pkg.AEKeypointsLoss(), torch.optim.SGD(net.parameters(), lr=0.0))
+    metrics, results = module.validation_step(batch)
+    assert set(metrics) == {"loss", "hm_0_loss", "hm_1_loss", "push_0_loss", "pull_0_loss"} and all(np.isfinite(v) for v in metrics.values())
+    assert abs(metrics["loss"] - (metrics["hm_0_loss"] + metrics["hm_1_loss"] + metrics["push_0_loss"] + metrics["pull_0_loss"])) < 1e-5 * max(1.0, metrics["loss"])
+    assert len(results) == B and all(not p.requires_grad or p.grad is None for p in net.parameters())
+    (g_hq, g_hh), g_tags = net(batch[0])
+    for b, r in enumerate(results):
+        assert isinstance(r, res_mod.KeypointsResult) and r.max_num_people == 20 and r.det_thr == 0.1 and r.tag_thr == 1.0
+        oj, os_ = orc.decode(g_hq[b].cpu().numpy(), g_hh[b].cpu().numpy(), [g_tags[b].cpu().numpy()], max_people=20, det_thr=0.1, tag_thr=1.0)
+        assert np.array_equal(r.kpts_coords, oj[..., :2]) and np.array_equal(r.kpts_scores, oj[..., 2]) and np.array_equal(r.obj_scores, os_)
+        one = res_mod.KeypointsResult(r.model_input_image, r._kpts_heatmaps, r._tags_heatmaps, r.limbs, 20, 0.1, 1.0)
+        one.set_preds()
+        assert np.array_equal(one.kpts_coords, r.kpts_coords) and np.array_equal(one.kpts_tags, r.kpts_tags) and np.array_equal(one.obj_scores, r.obj_scores)
+
+
 def _loss_case(pkg, case):
     tag, B, size, people, seed, holes = case
     hms, masks, joints = pkg.synth.synth_train_targets(B, 17, size, people, seed=seed, mask_holes=holes)
