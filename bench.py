@@ -362,6 +362,7 @@ def main():
             d = per_cfg[dom]
             cfgv = (C.c_int * 7)()
             kname = {100: "bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)",
+                     105: "bb_fp8_kernel (fused e4m3 BasicBlock: conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU)",
                      104: "bb128_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=128)",
                      103: "bb64_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=64)",
                      102: "stem_conv_kernel (fp32 NCHW -> conv3x3 s2 3->64 + BN + ReLU -> bf16 NHWC)",

@@ -197,7 +197,7 @@ struct Builder {
     }
     // four BasicBlocks "<prefix>.<u>" on tensor x with scratch m (both C channels); result ends in x
     // `nscales` = number of resolution branches running beside this one (0: no siblings, e.g. the deconv head)
-    void basic_blocks(const std::string &prefix, int C, int x, int m, int nscales = 0)
+    void basic_blocks(const std::string &prefix, int C, int x, int m, int nscales = 0, int branch = 0)
     {
         // The fused 128-channel block (basicblock_fused_c128.hip: 25.7 us per block against 2 x 18.4 us layer by layer when the
         // kernels run one at a time) is OFF by default: with the branch lanes running side by side it loses -- one box, two
@@ -208,7 +208,8 @@ struct Builder {
         const bool bb128 = C == 128 && e128 && (!strcmp(e128, "all") || (!strcmp(e128, "stage2") && nscales == 3));
         for (int u = 0; u < 4; ++u) {
             const std::string up = prefix + "." + std::to_string(u);
-            if ((C == 32 || (C == 64 && !getenv("HH_NO_BB64")) || bb128) && n.dtype != 2) {  // fused kernels, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
+            const bool fused_fp8 = n.dtype == 2 && bb_fp8_supported(C) && branch == 0 && !getenv("HH_NO_BB_FP8");  // highest-resolution branch / deconv head
+            if (((C == 32 || (C == 64 && !getenv("HH_NO_BB64")) || bb128) && n.dtype != 2) || fused_fp8) {  // fused kernels, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
                 Op o;
                 o.kind = OP_BB;
                 o.layer = L(up + ".conv1", up + ".bn1", C, C, 3, 1);
@@ -304,7 +305,7 @@ struct Builder {
                 const std::string hp = sp + ".blocks." + std::to_string(2 * b);
                 for (int i = 0; i < nsc; ++i) {  // branches are independent (hrnet.py:154-163): one lane each
                     lane = i;
-                    basic_blocks(hp + ".scales_blocks." + std::to_string(i), w[i], x[i], m[i], nsc);
+                    basic_blocks(hp + ".scales_blocks." + std::to_string(i), w[i], x[i], m[i], nsc, i);
                 }
                 lane = 0;
                 join(nsc);  // every fusion output reads every branch
@@ -805,6 +806,22 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             break;
         }
         case OP_BB: {
+            if (dtype == 2) {
+                ProfRecord *pr = nullptr;
+                if (prof_enabled) {
+                    if (prof_used == prof.size()) {
+                        ProfRecord r{};
+                        HH_CHECK_HIP(hipEventCreate(&r.e0));
+                        HH_CHECK_HIP(hipEventCreate(&r.e1));
+                        prof.push_back(r);
+                    }
+                    pr = &prof[prof_used++];
+                    pr->op = (int)(&op - ops.data());
+                    pr->slot = -1;
+                }
+                if (enqueue_fp8_bb(op, B, H, W, s, pr)) return 1;
+                break;
+            }
             const ConvLayer &l1 = layers[op.layer], &l2 = layers[op.layer2];
             const TensorDesc &ti = tensors[op.in], &to = tensors[op.out];
             BBParams p{};

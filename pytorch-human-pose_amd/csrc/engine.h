@@ -75,6 +75,7 @@ struct Op {
     int dep_from = 0; // OP_DEP: `lane` waits for everything enqueued so far on lane dep_from
     // fp8 path: tensor scales seen by this op (real value = e4m3 * scale), resolved from the calibration maxima
     float s_in = 1.f, s_in2 = 1.f, s_res = 1.f, s_out = 1.f, s_up[3] = {1.f, 1.f, 1.f};
+    float s_mid = 1.f;  // fused fp8 BasicBlock: scale of the intermediate tile
     int amax_slot = -1;  // index into hh_net::d_amax of this op's output maximum
 };
 
@@ -137,7 +138,8 @@ struct hh_net {
     bool calibrated = false;      // activation scales set (hh_calibrate)
     bool calibrating = false;     // the running forward records per-op output maxima
     unsigned *d_amax = nullptr;   // [ops.size()] bits of max |y| per op (calibration forwards only)
-    std::vector<float> amax;      // host copy, kept over the calibration rounds (running maximum)
+    std::vector<float> amax;      // host copy, kept over the calibration rounds (running maximum); [2 * ops]: the second half holds the
+                                  // intermediate-tile maxima of fused BasicBlocks
     int elem() const { return dtype == 2 ? 1 : 2; }  // bytes per activation element
 
     int build();
@@ -153,6 +155,7 @@ struct hh_net {
     int resolve_scales();  // amax -> per-op scales (plan order), d_mult of every layer
     int enqueue_fp8_conv(const Op &op, int B, int H, int W, float *o1, float *o2, hipStream_t s, ProfRecord *pr);
     int enqueue_fp8_upadd(const Op &op, int B, int H, int W, hipStream_t s);
+    int enqueue_fp8_bb(const Op &op, int B, int H, int W, hipStream_t s, ProfRecord *pr);
     void release_workspace();
     ~hh_net();
 };

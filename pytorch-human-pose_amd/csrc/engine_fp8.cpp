@@ -147,10 +147,10 @@ int hh_net::finalize_fp8()
         HH_CHECK_HIP(hipMemcpy(l.d_w, packed.data(), packed.size(), hipMemcpyHostToDevice));
         HH_CHECK_HIP(hipMemcpy(l.d_bias, shift.data(), (size_t)coutp * 4, hipMemcpyHostToDevice));
     }
-    if (!d_amax) HH_CHECK_HIP(hipMalloc((void **)&d_amax, ops.size() * 4));
+    if (!d_amax) HH_CHECK_HIP(hipMalloc((void **)&d_amax, 2 * ops.size() * 4));
     calibrated = false;  // new weights: the activation ranges may have moved
-    amax.assign(ops.size(), 0.f);
-    for (auto &op : ops) { op.s_in = op.s_in2 = op.s_res = op.s_out = 1.f; op.s_up[0] = op.s_up[1] = op.s_up[2] = 1.f; }
+    amax.assign(2 * ops.size(), 0.f);
+    for (auto &op : ops) { op.s_in = op.s_in2 = op.s_res = op.s_out = op.s_mid = 1.f; op.s_up[0] = op.s_up[1] = op.s_up[2] = 1.f; }
     return resolve_scales();
 }
 
@@ -188,6 +188,18 @@ int hh_net::resolve_scales()
             HH_CHECK_HIP(hipMemcpy(l.d_mult, mult.data(), mult.size() * 4, hipMemcpyHostToDevice));
             break;
         }
+        case OP_BB: {  // fused BasicBlock: conv1 -> intermediate (its own scale) -> conv2 + residual
+            op.s_in = cur[op.in];
+            op.s_mid = scale_of(amax[ops.size() + i]);
+            op.s_out = scale_of(amax[i]);
+            cur[op.out] = op.s_out;
+            ConvLayer &l1 = layers[op.layer], &l2 = layers[op.layer2];
+            std::vector<float> m1(l1.w_scale.size(), 0.f), m2(l2.w_scale.size(), 0.f);
+            for (int co = 0; co < l1.cout; ++co) { m1[co] = op.s_in * l1.w_scale[co]; m2[co] = op.s_mid * l2.w_scale[co]; }
+            HH_CHECK_HIP(hipMemcpy(l1.d_mult, m1.data(), m1.size() * 4, hipMemcpyHostToDevice));
+            HH_CHECK_HIP(hipMemcpy(l2.d_mult, m2.data(), m2.size() * 4, hipMemcpyHostToDevice));
+            break;
+        }
         case OP_UPADD:
             op.s_in = cur[op.in];
             for (int j = 0; j < op.nup; ++j) op.s_up[j] = cur[op.up[j]];
@@ -220,16 +232,16 @@ int hh_net::calibrate(const float *images, int B, int H, int W, int rounds, hipS
     HH_CHECK_HIP(hipMalloc((void **)&o2, (size_t)B * K * (H / 2) * (W / 2) * 4));
     int rc = 0;
     for (int r = 0; r < rounds && !rc; ++r) {
-        HH_CHECK_HIP(hipMemsetAsync(d_amax, 0, ops.size() * 4, s));
+        HH_CHECK_HIP(hipMemsetAsync(d_amax, 0, 2 * ops.size() * 4, s));
         calibrating = true;
         lastB = B; lastH = H; lastW = W;
         rc = enqueue(images, B, H, W, o1, o2, s);
         calibrating = false;
         if (rc) break;
         HH_CHECK_HIP(hipStreamSynchronize(s));
-        std::vector<unsigned> bits(ops.size());
+        std::vector<unsigned> bits(2 * ops.size());
         HH_CHECK_HIP(hipMemcpy(bits.data(), d_amax, bits.size() * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < ops.size(); ++i) {
+        for (size_t i = 0; i < bits.size(); ++i) {
             float f;
             memcpy(&f, &bits[i], 4);
             if (f == f && std::isfinite(f)) amax[i] = std::max(amax[i], f);
@@ -307,5 +319,27 @@ int hh_net::enqueue_fp8_upadd(const Op &op, int B, int H, int W, hipStream_t s)
     p.B = B; p.H = H >> b.shift; p.W = W >> b.shift; p.C = round_up(op.C, 16); p.relu = op.relu;
     if (calibrating) p.absmax = d_amax + (&op - ops.data());
     HH_CHECK_HIP(launch_upadd_fp8(p, s));
+    return 0;
+}
+
+int hh_net::enqueue_fp8_bb(const Op &op, int B, int H, int W, hipStream_t s, ProfRecord *pr)
+{
+    const ConvLayer &l1 = layers[op.layer], &l2 = layers[op.layer2];
+    const TensorDesc &ti = tensors[op.in], &to = tensors[op.out];
+    Fp8BBParams p{};
+    p.in = (const unsigned char *)ti.ptr; p.in_cs = ti.C; p.out = (unsigned char *)to.ptr; p.out_cs = to.C;
+    p.w1 = (const unsigned char *)l1.d_w; p.w2 = (const unsigned char *)l2.d_w;
+    p.mult1 = l1.d_mult; p.bias1 = l1.d_bias; p.mult2 = l2.d_mult; p.bias2 = l2.d_bias;
+    p.mid_inv_scale = 1.f / op.s_mid; p.res_scale = op.s_in; p.out_inv_scale = 1.f / op.s_out;
+    p.B = B; p.H = H >> ti.shift; p.W = W >> ti.shift;
+    if (calibrating) { p.amax_out = d_amax + (&op - ops.data()); p.amax_mid = d_amax + ops.size() + (&op - ops.data()); }
+    if (pr) {
+        const double Cb = l1.cout;
+        pr->cfg = HH_CFG_BB_FP8;
+        pr->flops = 2.0 * 2.0 * B * p.H * p.W * Cb * Cb * 9.0;
+        pr->bytes = 2.0 * B * p.H * p.W * Cb + 2.0 * 9 * Cb * Cb;
+        hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};
+    }
+    HH_CHECK_HIP(bb_fp8_launch(l1.cout, p, num_cus, s));
     return 0;
 }

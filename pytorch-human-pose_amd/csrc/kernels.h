@@ -122,6 +122,21 @@ const Fp8ConvConfig &conv_fp8_config(int i);
 hipError_t conv_fp8_launch(int cfg_index, const Fp8ConvParams &p, hipStream_t stream);
 hipError_t conv_fp8_init();
 
+// fused BasicBlock on e4m3 tensors (basicblock_fused_fp8.hip): weights packed as conv_fp8 packs a 3x3 conv with KC = C, NT = 2
+struct Fp8BBParams {
+    const unsigned char *in; int in_cs;   // [B,H,W,in_cs bytes], channels 0..C-1
+    unsigned char *out; int out_cs;       // must not alias `in`
+    const unsigned char *w1, *w2;
+    const float *mult1, *bias1, *mult2, *bias2;  // [64]: s_in * s_w1[co], shift1, s_mid * s_w2[co], shift2 (0 for padding couts)
+    float mid_inv_scale, res_scale, out_inv_scale;
+    int B, H, W;
+    int tiles_x, tiles_y, ntiles;         // filled by the launcher
+    unsigned *amax_mid, *amax_out;        // calibration (NULL = off): atomicMax of the bits of the tensors' maxima
+};
+bool bb_fp8_supported(int C);
+hipError_t bb_fp8_launch(int C, const Fp8BBParams &p, int num_cus, hipStream_t s);
+#define HH_CFG_BB_FP8 105
+
 // Fused 32-channel BasicBlock (basicblock_fused.hip): out = relu(conv2(relu(conv1(in))) + in), BN folded.
 struct BBParams {
     const bf16_raw *in; int in_cs;   // [B,H,W,in_cs], channels 0..31
