@@ -475,6 +475,10 @@ int hh_net::finalize()
     HH_CHECK_HIP(bb_fused_init());
     HH_CHECK_HIP(bb64_fused_init());
     HH_CHECK_HIP(bb128_fused_init());
+#ifdef HH_EXPERIMENTAL
+    HH_CHECK_HIP(bb_thin_init());
+    bb32_thin = getenv("HH_BB32") && !strcmp(getenv("HH_BB32"), "thin");
+#endif
     HH_CHECK_HIP(junction_init());
     if (dtype == 2 && kind != 0) { hh_set_error("hh_finalize: the fp8 path covers HigherHRNet only"); return 1; }
     {
@@ -848,6 +852,9 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             }
             if (l1.cout == 128) HH_CHECK_HIP(bb128_fused_launch(p, num_cus, s));
             else if (l1.cout == 64) HH_CHECK_HIP(bb64_fused_launch(p, num_cus, s));
+#ifdef HH_EXPERIMENTAL
+            else if (bb32_thin) HH_CHECK_HIP(bb_thin_launch(p, num_cus, s));
+#endif
             else HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
             break;
         }

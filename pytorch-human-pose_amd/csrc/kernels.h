@@ -154,6 +154,11 @@ struct BBParams {
 hipError_t bb_fused_init();
 hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s);
 // the same block for the 64-channel branch (basicblock_fused_c64.hip): weights packed KS=3,S=1,KC=32,NT=2 ([chunk][tap][4][64][8])
+// "thin" variant of the 32-channel block (experimental/basicblock_fused_thin.hip, EXPERIMENTAL=1 builds only): half a CU per
+// workgroup, weights in registers; measured SLOWER than basicblock_fused.hip (forward 5.67 vs 5.09 ms with the lanes, 6.54 vs
+// 5.99 ms serial, tools/probes/ab_thin.sh)
+hipError_t bb_thin_init();
+hipError_t bb_thin_launch(BBParams p, int num_cus, hipStream_t s);
 #define HH_CFG_BB128_FUSED 104
 // ... and for the 128-channel branch (basicblock_fused_c128.hip): weights packed KS=3,S=1,KC=16,COUT_T=128 ([chunk][tap][2][128][8])
 hipError_t bb128_fused_init();
