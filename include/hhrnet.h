@@ -114,6 +114,8 @@ int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, int cout, int
                         float *ms_per_launch, unsigned long long *stamps16, int ref_cfg, float *max_diff);
 
 int hh_debug_bb_bench(int B, int H, int W, int iters, float *ms_per_launch, unsigned long long *stamps64);
+/* the two fused 32-channel block kernels (tile form / producer-consumer form) on the same input: output difference and time */
+int hh_debug_bb_compare(int B, int H, int W, int iters, float *max_diff, float *ms_classic, float *ms_pc);
 
 /* Debug taps (parity tests): when enabled, hh_forward copies selected intermediate
  * activations; hh_tap_read converts one to fp32 NCHW on the host. Names follow the

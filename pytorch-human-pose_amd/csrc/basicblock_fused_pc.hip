@@ -1,0 +1,465 @@
+// Fused 32-channel BasicBlock, producer / consumer form:   out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x)
+// -- /root/reference/src/keypoints/architectures/hrnet.py:108-124 -- in ONE kernel, like basicblock_fused.hip, but
+// organised around the LDS instead of around the tile:
+//
+//   basicblock_fused.hip reads 1.3 ds_read_b128 per MFMA (every wave re-reads its weight fragments for every tile and
+//   conv1 reads one pixel fragment per MFMA), which together with the 13-cycle ds_write_b128 keeps the LDS ~85 % busy
+//   and the matrix cores ~40 %.  Here
+//     * waves 0-3 only ever run conv1 and waves 4-7 only conv2, so each wave keeps ITS conv's 18 weight fragments in
+//       72 VGPRs for the life of the (persistent) workgroup: no weight reads at all;
+//     * a wave owns a band of rows, and a pixel fragment (one row, one kx shift, one k half) feeds the three output rows
+//       it is a tap of (ky = 0..2): 6 reads per 12 MFMAs in a 4-row band;
+//   = 0.45 ds_read_b128 per MFMA.  The two groups work one tile apart (conv1 of tile t+1 beside conv2 of tile t) with one
+//   workgroup barrier per tile; wave w and wave w+4 share a SIMD, so one's epilogue VALU / LDS / store work sits under
+//   the other's MFMAs.
+//
+// Tile: 14x32 outputs, 16x34 mid pixels, 18x36 input patch; patch and mid tile are double buffered (157 KB of LDS), pixels
+// are 64 bytes (no padding): the 16-byte part index is XOR-swizzled by (x >> 2) & 3 (and by (row >> 1) & 3 in the
+// patch, whose rows are 38 pixels apart), which makes every ds_read_b128 below conflict-free, the column tile of the
+// two extra mid columns (lanes = 16 rows x 2 columns) included.
+// The residual is added in fp32 from global memory (the lines are L2-warm: the patch was fetched one tile earlier).
+#include "kernels.h"
+
+#include <utility>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_relu_bf16x2(float a, float b)
+{
+    f32x2 f = {a, b};
+    const i16x2 v = __builtin_bit_cast(i16x2, __builtin_convertvector(f, bf16x2));
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, i16x2{0, 0}));
+}
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// 32 couts of one pixel: lanes (r,0) hold couts 8g..8g+3, lanes (r,1) couts 8g+4..8g+7 in acc[4g..4g+3].
+// Returns for m = 0,1 the 16 bytes (bf16, ReLU applied) of couts 16m+8h .. 16m+8h+7 of this lane's pixel.
+__device__ __forceinline__ void pack_rows16(const f32x16 &acc, u32x4 out[2])
+{
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        unsigned x0 = pack_relu_bf16x2(acc[8 * m + 0], acc[8 * m + 1]), x1 = pack_relu_bf16x2(acc[8 * m + 2], acc[8 * m + 3]);
+        unsigned y0 = pack_relu_bf16x2(acc[8 * m + 4], acc[8 * m + 5]), y1 = pack_relu_bf16x2(acc[8 * m + 6], acc[8 * m + 7]);
+        auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+        out[m] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+    }
+}
+
+// LDS fragment reads whose place in the instruction stream and whose wait are fixed by hand.  Left to the compiler, the
+// reads of the software pipeline below end up right in front of their MFMAs (it renames the rotating fragment registers and
+// waits lgkmcnt(0)), which exposes a full LDS round trip per step.  The read is an asm statement (volatile: the statements keep
+// their order); its result may only be used through lds_wait<N>(), which waits until at most N younger LDS operations are
+// outstanding (LDS operations complete in order; compiler-issued ones in between only make the wait conservative).
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_async(int addr)
+{
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4 &v)
+{
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+constexpr int TH = 14, TW = 32;          // output tile
+constexpr int MH = TH + 2, MW = TW + 2;  // conv1 output (= conv2 input) tile: 16 x 34
+constexpr int IH = TH + 4, IW = TW + 4;  // input patch: 18 x 36
+constexpr int PRS = 38;                  // patch row stride in pixels (see the header: conflict-free edge tile)
+constexpr int NTHR = 512;
+constexpr int PATCH_BYTES = IH * PRS * 64;  // 43,776
+constexpr int MID_BYTES = MH * MW * 64;     // 34,816
+constexpr int P_UNITS = IH * IW * 4;        // 2592 16-byte units
+constexpr int NPL = (P_UNITS + NTHR - 1) / NTHR;  // 6 (the last round: 32 threads)
+// LDS fragment reads run RD steps (1-3 MFMAs each) ahead of the MFMAs that use them
+constexpr int RD = 2, NFB = RD + 1;     // producer
+constexpr int RDC = 4, NFBC = RDC + 1;  // consumer (more registers to spare)
+constexpr int RP = MH / 4;                  // mid rows per producer wave
+static_assert(MH % 4 == 0 && 2 * MH == 32, "4 producer bands; the two extra mid columns make exactly one 32-pixel column tile");
+constexpr int OFF_MID = 2 * PATCH_BYTES, OFF_BIAS = OFF_MID + 2 * MID_BYTES;
+constexpr int LDS_BYTES = OFF_BIAS + 256;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+}  // namespace
+
+#ifdef HH_STAMP  // phase stamps of workgroup 0, iteration 2 (steady state): 8 slots per wave
+#define PSTAMP(i) do { if (p.stamps && blockIdx.x == 0 && it == 2 && lane == 0) p.stamps[wave * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PSTAMP(i)
+#endif
+
+__global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+#ifndef HH_NO_CLK
+    if (p.clk && tid == 0) atomicMin(p.clk, wall_clock64());
+#endif
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const bool producer = wave < 4;
+    const int wj = wave & 3;
+
+    const size_t in_bytes = (((size_t)p.B * p.H * p.W - 1) * p.in_cs + 32) * 2, out_bytes = (((size_t)p.B * p.H * p.W - 1) * p.out_cs + 32) * 2;
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw *>(p.in), 0, (int)in_bytes, 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;  // a byte offset past every tensor here: the load returns 0, the store is dropped
+
+    // ---- this wave's weight fragments (A operand: 32 couts x 16 cin per (tap, k half)), resident in registers
+    u32x4 wreg[18];
+    {
+        const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw *>(producer ? p.w1 : p.w2), 0, 18432, 0x00020000);
+        static_for<18>([&](auto fc) {
+            constexpr int f = decltype(fc)::value, tap = f >> 1, kk = f & 1;
+            wreg[f] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, ((tap * 4 + kk * 2 + h) * 32 + r) * 16, 0, 0));
+        });
+    }
+    if (tid < 32) {
+        reinterpret_cast<float *>(smem + OFF_BIAS)[tid] = p.b1[tid];
+        reinterpret_cast<float *>(smem + OFF_BIAS)[32 + tid] = p.b2[tid];
+    }
+
+    // ---- tiles of this workgroup, XCD-aware order as in basicblock_fused.hip
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int nloc = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto band = [&](int i) { return ((p.ntiles & 7) == 0 && (gridDim.x & 7) == 0) ? (i & 7) * (p.ntiles >> 3) + (i >> 3) : i; };
+    struct Geom { int b, oy0, ox0; };
+    auto geom = [&](int k) {  // k-th tile of this workgroup
+        const int tb = band((int)blockIdx.x + k * (int)gridDim.x);
+        const int b = tb / tiles_per_img, tt = tb % tiles_per_img;
+        return Geom{b, (tt / p.tiles_x) * TH, (tt % p.tiles_x) * TW};
+    };
+
+    // ---- patch prefetch: global -> registers (issued early in an iteration) -> LDS (late in the same iteration).
+    // Round i of 6 moves patch rows 3i..3i+2 (432 16-byte units: threads 0..431; unit = (row 3i + tid / 144, pixel (tid % 144) >> 2,
+    // part tid & 3)), so a thread's six units differ only by a row step: one address each side per thread, a scalar step per
+    // round -- the vector-instruction budget of this kernel is as tight as its MFMA budget.
+    u32x4 preg[NPL];
+    static_assert(NPL * 3 == IH && IW * 4 * 3 <= NTHR, "six rounds of three patch rows");
+    const int pu_row = tid / (IW * 4), pu_cu = tid - pu_row * (IW * 4), pu_px = pu_cu >> 2;
+    const bool pu_act = tid < IW * 4 * 3;
+    const int pu_key = (pu_cu ^ (pu_px >> 2)) & 3;                 // part ^ x key; the row key is XORed in per round
+    const int pu_lbase = (pu_row * PRS + pu_px) * 64;
+    const int pf_rowstep = 3 * p.W * p.in_cs * 2;
+    unsigned pf_vbase = 0;  // byte offset of this thread's round-0 unit
+    int pf_y = 0;           // image row of that unit
+    bool pf_xok = false;
+    auto pf_setup = [&](int k) {
+        const bool on = k < nloc;
+        const Geom g = geom(on ? k : 0);
+        const int ix = g.ox0 - 2 + pu_px;
+        pf_y = g.oy0 - 2 + pu_row;
+        pf_xok = on & pu_act & ((unsigned)ix < (unsigned)p.W);
+        pf_vbase = (unsigned)(((g.b * p.H + pf_y) * p.W + ix) * p.in_cs * 2 + (pu_cu & 3) * 16);
+    };
+    auto pf_load = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const bool ok = pf_xok & ((unsigned)(pf_y + 3 * i) < (unsigned)p.H);
+        const unsigned voff = ok ? pf_vbase + (unsigned)(i * pf_rowstep) : OOB;  // outside the image: zero = conv1's padding
+#ifdef BBPC_NOLOAD  // timing experiment: no patch traffic (results are wrong)
+        preg[i] = u32x4{voff, 0u, 0u, 0u};
+#else
+        preg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)voff, 0, 0));
+#endif
+    };
+    auto pf_write = [&](auto ic, int patch_off) {
+        constexpr int i = decltype(ic)::value;
+        if (pu_act)
+            *reinterpret_cast<u32x4 *>(smem + patch_off + pu_lbase + 3 * i * PRS * 64 + (((pu_key ^ ((pu_row + 3 * i) >> 1)) & 3) << 4)) = preg[i];
+    };
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    pf_setup(0);
+    static_for<NPL>(pf_load);
+    static_for<NPL>([&](auto ic) { pf_write(ic, 0); });
+    __syncthreads();
+
+    // ---- per-lane LDS read bases (buffer 0; the buffer offset is added per iteration)
+    // patch, main column tiles: pixel (4 wj + i, r + kx), part kk*2 + h; the row key (2 wj + (i >> 1)) & 3 is XORed in per read
+    int pa0[3][2], ma0[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int x = r + kx;
+            pa0[kx][kk] = (4 * wj * PRS + x) * 64 + ((((kk * 2 + h) ^ (x >> 2)) & 3) << 4);
+            ma0[kx][kk] = x * 64 + ((((kk * 2 + h) ^ (x >> 2)) & 3) << 4);  // + consumer row base below
+        }
+    const int c0 = wj < 2 ? 4 * wj : 8 + 3 * (wj - 2);  // consumer bands: rows 0-3, 4-7, 8-10, 11-13
+    const int kb[3] = {((2 * wj) & 3) << 4, ((2 * wj + 1) & 3) << 4, ((2 * wj + 2) & 3) << 4};
+
+    // The two roles run separate copies of the tile loop (one barrier per iteration each, nloc + 1 iterations both), so
+    // that neither carries the other's addresses and accumulators in its register budget.
+    //
+    // Inside an iteration the two waves of a SIMD are in ANTIPHASE: the producer runs its MFMAs first and its epilogue
+    // (pack, ReLU, LDS writes) second; the consumer first finishes the tile of the iteration before (residual, pack, stores:
+    // its accumulators survive the barrier) and only then starts its MFMAs.  Each one's vector / LDS / store work then sits
+    // under the other's MFMAs instead of both groups converting and storing side by side at the end of the iteration.
+    auto bias_acc = [&](int off) {
+        f32x16 b0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = *reinterpret_cast<const float4 *>(smem + OFF_BIAS + (off + 8 * q + 4 * h) * 4);
+            b0[4 * q + 0] = bv.x; b0[4 * q + 1] = bv.y; b0[4 * q + 2] = bv.z; b0[4 * q + 3] = bv.w;
+        }
+        return b0;
+    };
+    if (producer) {
+        auto produce = [&](auto edgec, int it) {
+            constexpr bool EDGE = decltype(edgec)::value;  // wave 3 also owns the column tile of the two extra mid columns
+            const int pcur = (it & 1) * PATCH_BYTES, pnext = ((it + 1) & 1) * PATCH_BYTES;
+            const Geom g = geom(it);
+            const int mcur = OFF_MID + (it & 1) * MID_BYTES;
+            f32x16 acc[RP + (EDGE ? 1 : 0)];
+            const f32x16 b0 = bias_acc(0);  // the C operand of every accumulator's first MFMA (no copies)
+            // lane r of the edge tile = (mid row r >> 1, mid column 32 + (r & 1)); (x >> 2) & 3 == 0 for patch columns 32..35
+            const int mrow = r >> 1, mcol = MW - 2 + (r & 1);
+            int ea[3][2];
+            if constexpr (EDGE) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        ea[ky][kk] = pcur + ((mrow + ky) * PRS + mcol) * 64 + ((((kk * 2 + h) ^ ((mrow + ky) >> 1)) & 3) << 4);
+            }
+            // wave 3 runs the edge tile FIRST (18 MFMAs into one accumulator, packed and written while the main rows' MFMAs run):
+            // five live accumulators next to the weights and the prefetch registers do not fit in 256 VGPRs
+            constexpr int NR = RP + 2, NE = EDGE ? 18 : 0, NM = 6 * NR, NS = NE + NM;
+            u32x4 fb[NFB];
+            auto ldb = [&](auto sc, int buf) {
+                constexpr int s = decltype(sc)::value;
+                if constexpr (s >= NE) {
+                    constexpr int c = (s - NE) / NR, i = (s - NE) % NR, kx = c >> 1, kk = c & 1;
+                    fb[buf] = lds_read_async<i * PRS * 64>(pcur + (pa0[kx][kk] ^ kb[i >> 1]));
+                } else {
+                    constexpr int tap = s >> 1, kk = s & 1, ky = tap / 3, kx = tap % 3;
+                    fb[buf] = lds_read_async<kx * 64>(ea[ky][kk]);
+                }
+            };
+            auto edge_out = [&]() {
+                if constexpr (!EDGE) return;
+                const int gy = g.oy0 - 1 + mrow, gxe = g.ox0 - 1 + mcol;
+                const bool outside = ((unsigned)gy >= (unsigned)p.H) | ((unsigned)gxe >= (unsigned)p.W);
+                u32x4 o[2];
+                pack_rows16(acc[RP + (EDGE ? 0 : -1)], o);
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+                    *reinterpret_cast<u32x4 *>(smem + mcur + (mrow * MW + mcol) * 64 + ((2 * mm + h) << 4)) = outside ? u32x4{0u, 0u, 0u, 0u} : o[mm];
+            };
+            static_for<RD>([&](auto sc) { ldb(sc, decltype(sc)::value); });
+            static_for<NS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                if constexpr (s + RD < NS) {
+                    ldb(std::integral_constant<int, s + RD>{}, (s + RD) % NFB);
+                }
+                if constexpr (s < NPL) pf_load(sc);
+                lds_wait<(NS - 1 - s < RD ? NS - 1 - s : RD)>(fb[s % NFB]);
+                if constexpr (EDGE && s == NE + 2) edge_out();
+                if constexpr (s >= NE) {
+                    constexpr int c = (s - NE) / NR, i = (s - NE) % NR, kx = c >> 1, kk = c & 1;
+                    constexpr int nm = (i == 0 || i == NR - 1) ? 1 : ((i == 1 || i == NR - 2) ? 2 : 3);
+                    static_for<3>([&](auto kyc) {
+                        constexpr int ky = decltype(kyc)::value, j = i - ky;
+                        if constexpr (j >= 0 && j < RP)
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[(ky * 3 + kx) * 2 + kk]),
+                                                                             __builtin_bit_cast(bf16x8, fb[s % NFB]),
+                                                                             (c == 0 && ky == 0) ? b0 : acc[j], 0, 0, 0);
+                    });
+                    __builtin_amdgcn_sched_group_barrier(0x8, nm, 0);
+                } else {
+                    constexpr int ie = RP + (EDGE ? 0 : -1);  // (only instantiated with EDGE)
+                    acc[ie] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[s]), __builtin_bit_cast(bf16x8, fb[s % NFB]),
+                                                                      s == 0 ? b0 : acc[ie], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                }
+            });
+            PSTAMP(1);
+            // mid rows -> LDS (bf16, ReLU).  Mid pixels outside the image are conv2's zero padding, not conv1(padding): whole rows
+            // (wave-uniform), column -1 (lane 0 of the left-most tiles) and, in ragged widths only, columns >= W.
+            const bool ragged = g.ox0 + TW - 1 > p.W;  // wave-uniform: some main column ox0 - 1 + r is >= W
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                const int m = 4 * wj + j, gy = g.oy0 - 1 + m;
+                u32x4 o[2];
+                pack_rows16(acc[j], o);
+                if ((unsigned)gy >= (unsigned)p.H) o[0] = o[1] = u32x4{0u, 0u, 0u, 0u};
+                else if (ragged) {
+                    const bool outside = g.ox0 - 1 + r >= p.W;
+                    o[0] = outside ? u32x4{0u, 0u, 0u, 0u} : o[0];
+                    o[1] = outside ? u32x4{0u, 0u, 0u, 0u} : o[1];
+                }
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+                    *reinterpret_cast<u32x4 *>(smem + mcur + (m * MW + r) * 64 + ((((2 * mm + h) ^ (r >> 2)) & 3) << 4)) = o[mm];
+            }
+            if (g.ox0 == 0 && r == 0) {  // column -1
+#pragma unroll
+                for (int j = 0; j < RP; ++j)
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm)
+                        *reinterpret_cast<u32x4 *>(smem + mcur + ((4 * wj + j) * MW) * 64 + ((2 * mm + h) << 4)) = u32x4{0u, 0u, 0u, 0u};
+            }
+            static_for<NPL>([&](auto ic) { pf_write(ic, pnext); });  // the next patch (loads issued at the top of the MFMA loop)
+        };
+        for (int it = 0; it <= nloc; ++it) {
+            pf_setup(it + 1);
+            PSTAMP(0);
+            if (it < nloc) {
+                if (wj == 3) produce(std::true_type{}, it);
+                else produce(std::false_type{}, it);
+            }  // (last iteration: nothing to produce and nothing to prefetch)
+            PSTAMP(3);
+            lds_barrier();
+            PSTAMP(4);
+        }
+    } else {
+        // One instantiation of the whole consumer loop per band height (waves 4, 5: 4 rows; waves 6, 7: 3 rows).
+        auto consumer_loop = [&](auto rcc) {
+            constexpr int RC = decltype(rcc)::value;
+            f32x16 acc[RC];
+            // finish the tile whose MFMAs ran in the previous iteration: ReLU, bf16, 16-byte stores (the residual went into the
+            // accumulators' initial value)
+            auto finish = [&](int k) {
+                const Geom g = geom(k);
+                const int ox = g.ox0 + r;
+#pragma unroll
+                for (int j = 0; j < RC; ++j) {
+                    const int oy = g.oy0 + c0 + j;
+                    u32x4 o[2];
+                    pack_rows16(acc[j], o);
+                    const bool ok = (oy < p.H) & (ox < p.W);
+#ifdef BBPC_NOSTORE
+                    const unsigned voff = (ok && o[0][0] == 0x12345678u) ? (unsigned)(((g.b * p.H + oy) * p.W + ox) * p.out_cs * 2 + 16 * h) : OOB;
+#else
+                    const unsigned voff = ok ? (unsigned)(((g.b * p.H + oy) * p.W + ox) * p.out_cs * 2 + 16 * h) : OOB;
+#endif
+                    __builtin_amdgcn_raw_buffer_store_b128(o[0], rs_out, (int)voff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o[1], rs_out, (int)voff, 32, 0);
+                }
+            };
+            for (int it = 0; it <= nloc; ++it) {
+                pf_setup(it + 1);
+                PSTAMP(0);
+                // residual of the tile about to be convolved, in flight (like the next patch) under the stores of finish(); then the
+                // accumulators start as shift + residual.  Loaded as the output is stored -- 16 bytes per lane, channels 16m + 8h .. +7 of
+                // pixel (oy, ox0 + r): a wave instruction touches 32 half lines; 8-byte pieces in accumulator order touch 64 lines each and
+                // kept the CU's address path busy for ~1000 cycles per wave and tile -- and brought into accumulator order (couts
+                // 8q + 4h .. +3) by the inverse of pack_rows16's lane swap.
+                u32x4 res[RC][2];
+                const Geom g = geom(it >= 1 ? it - 1 : 0);
+                if (it >= 1) {
+                    const int ox = g.ox0 + r;
+#pragma unroll
+                    for (int j = 0; j < RC; ++j) {
+                        const int oy = g.oy0 + c0 + j;
+                        const bool ok = (oy < p.H) & (ox < p.W);
+                        const unsigned voff = ok ? (unsigned)(((g.b * p.H + oy) * p.W + ox) * p.in_cs * 2 + 16 * h) : OOB;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#ifdef BBPC_NORES
+                            res[j][m] = u32x4{voff, 0u, 0u, 0u};
+#else
+                            res[j][m] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)voff, 32 * m, 0));
+#endif
+                    }
+                }
+                static_for<NPL>(pf_load);  // the next patch: written to LDS late in the MFMA loop
+                if (it >= 2) finish(it - 2);
+                PSTAMP(1);
+                const int pnext = ((it + 1) & 1) * PATCH_BYTES;
+                if (it >= 1) {
+                    const int mcur = OFF_MID + ((it - 1) & 1) * MID_BYTES + c0 * MW * 64;
+                    {
+                        const f32x16 b0 = bias_acc(32);
+#pragma unroll
+                        for (int j = 0; j < RC; ++j)
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                // lanes h = 0 hold channels 16m .. +7, lanes h = 1 channels 16m + 8 .. +15; swap (h = 0: dwords 2, 3) with
+                                // (h = 1: dwords 0, 1): then dwords 0, 1 are q = 2m and dwords 2, 3 are q = 2m + 1 in both halves
+                                auto s0 = __builtin_amdgcn_permlane32_swap(res[j][m][0], res[j][m][2], false, false);
+                                auto s1 = __builtin_amdgcn_permlane32_swap(res[j][m][1], res[j][m][3], false, false);
+                                const unsigned d[4] = {s0[0], s1[0], s0[1], s1[1]};
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    acc[j][8 * m + 2 * t + 0] = b0[8 * m + 2 * t + 0] + __uint_as_float(d[t] << 16);
+                                    acc[j][8 * m + 2 * t + 1] = b0[8 * m + 2 * t + 1] + __uint_as_float(d[t] & 0xffff0000u);
+                                }
+                            }
+                    }
+                    constexpr int NR = RC + 2, NS = 6 * NR;
+                    u32x4 fb[NFBC];
+                    auto ldb = [&](auto sc, int buf) {
+                        constexpr int s = decltype(sc)::value, c = s / NR, i = s % NR, kx = c >> 1, kk = c & 1;
+                        fb[buf] = lds_read_async<i * MW * 64>(mcur + ma0[kx][kk]);
+                    };
+                    static_for<RDC>([&](auto sc) { ldb(sc, decltype(sc)::value); });
+                            static_for<NS>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value, c = s / NR, i = s % NR, kx = c >> 1, kk = c & 1;
+                        if constexpr (s + RDC < NS) {
+                            ldb(std::integral_constant<int, s + RDC>{}, (s + RDC) % NFBC);
+                                }
+                        if constexpr (s >= NS - 12 && s - (NS - 12) < NPL) {
+                            pf_write(std::integral_constant<int, s - (NS - 12)>{}, pnext);
+                            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        }
+                        lds_wait<(NS - 1 - s < RDC ? NS - 1 - s : RDC)>(fb[s % NFBC]);
+                        constexpr int nm = (i == 0 || i == NR - 1) ? 1 : ((i == 1 || i == NR - 2) ? 2 : 3);
+                        static_for<3>([&](auto kyc) {
+                            constexpr int ky = decltype(kyc)::value, j = i - ky;
+                            if constexpr (j >= 0 && j < RC)
+                                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[(ky * 3 + kx) * 2 + kk]),
+                                                                                 __builtin_bit_cast(bf16x8, fb[s % NFBC]), acc[j], 0, 0, 0);
+                        });
+                        __builtin_amdgcn_sched_group_barrier(0x8, nm, 0);
+                    });
+                } else {
+                    static_for<NPL>([&](auto ic) { pf_write(ic, pnext); });
+                }
+                PSTAMP(3);
+                lds_barrier();
+                PSTAMP(4);
+            }
+            finish(nloc - 1);
+        };
+        if (wj < 2) consumer_loop(std::integral_constant<int, 4>{});
+        else consumer_loop(std::integral_constant<int, 3>{});
+    }
+#ifndef HH_NO_CLK
+    if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
+#endif
+}
+
+hipError_t bbpc_init()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(bbpc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+}
+
+hipError_t bbpc_launch(BBParams p, int num_cus, hipStream_t s)
+{
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    if ((size_t)p.B * p.H * p.W * (size_t)(p.in_cs > p.out_cs ? p.in_cs : p.out_cs) * 2 >= 0x7fffffffull) return hipErrorInvalidValue;  // 32-bit buffer offsets
+    const int grid = p.ntiles < num_cus ? p.ntiles : num_cus;
+    HH_LAUNCH(bbpc_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, s, p);
+    return hipGetLastError();
+}

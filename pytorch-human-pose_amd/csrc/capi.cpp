@@ -569,6 +569,88 @@ extern "C" int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, in
     return 0;
 }
 
+// A/B of the two fused 32-channel blocks on the same random input (H, W need not be tile multiples): the largest absolute
+// difference of the outputs (both round to bf16, the accumulation orders differ: expect a few bf16 ulps) and the time per launch.
+extern "C" int hh_debug_bb_compare(int B, int H, int W, int iters, float *max_diff, float *ms_classic, float *ms_pc)
+{
+    HH_CHECK_HIP(conv_init());
+    HH_CHECK_HIP(bb_fused_init());
+    HH_CHECK_HIP(bbpc_init());
+    const size_t n = (size_t)B * H * W * 32;
+    std::vector<bf16_raw> h_in(n), h_w(2 * 9 * 32 * 32), h_o1(n), h_o2(n);
+    std::vector<float> h_b(64);
+    uint32_t s = 4242u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (bf16_raw)(0x3c00u + ((s >> 16) & 0x1ffu) + ((s >> 30) << 15)); };  // +-[0.0078, 0.031)
+    for (auto &v : h_in) v = (bf16_raw)(rnd() + 0x0300u);
+    for (auto &v : h_w) v = rnd();
+    for (auto &v : h_b) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 20) - 2048) * 1e-4f; }
+    bf16_raw *d_in, *d_o1, *d_o2, *d_w;
+    float *d_b;
+    HH_CHECK_HIP(hipMalloc((void **)&d_in, n * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_o1, n * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_o2, n * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_w, h_w.size() * 2));
+    HH_CHECK_HIP(hipMalloc((void **)&d_b, 64 * 4));
+    HH_CHECK_HIP(hipMemcpy(d_in, h_in.data(), n * 2, hipMemcpyHostToDevice));
+    HH_CHECK_HIP(hipMemcpy(d_w, h_w.data(), h_w.size() * 2, hipMemcpyHostToDevice));
+    HH_CHECK_HIP(hipMemcpy(d_b, h_b.data(), 64 * 4, hipMemcpyHostToDevice));
+    HH_CHECK_HIP(hipMemset(d_o1, 0xff, n * 2));
+    HH_CHECK_HIP(hipMemset(d_o2, 0xff, n * 2));
+    BBParams p{};
+    p.in = d_in; p.in_cs = 32; p.out_cs = 32; p.w1 = d_w; p.w2 = d_w + 9 * 32 * 32; p.b1 = d_b; p.b2 = d_b + 32;
+    p.B = B; p.H = H; p.W = W;
+    unsigned long long *d_st = nullptr;
+    HH_CHECK_HIP(hipMalloc((void **)&d_st, 64 * 8));
+    HH_CHECK_HIP(hipMemset(d_st, 0, 64 * 8));
+    p.stamps = d_st;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HH_CHECK_HIP(hipGetDevice(&dev));
+    HH_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    hipStream_t st;
+    HH_CHECK_HIP(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    HH_CHECK_HIP(hipEventCreate(&e0));
+    HH_CHECK_HIP(hipEventCreate(&e1));
+    float ms[2] = {0, 0};
+    for (int v = 0; v < 2; ++v) {
+        p.out = v ? d_o2 : d_o1;
+        auto go = [&]() { return v ? bbpc_launch(p, prop.multiProcessorCount, st) : bb_fused_launch(p, prop.multiProcessorCount, st); };
+        for (int i = 0; i < 3; ++i) HH_CHECK_HIP(go());
+        HH_CHECK_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) HH_CHECK_HIP(go());
+        HH_CHECK_HIP(hipEventRecord(e1, st));
+        HH_CHECK_HIP(hipEventSynchronize(e1));
+        HH_CHECK_HIP(hipEventElapsedTime(&ms[v], e0, e1));
+    }
+    HH_CHECK_HIP(hipMemcpy(h_o1.data(), d_o1, n * 2, hipMemcpyDeviceToHost));
+    HH_CHECK_HIP(hipMemcpy(h_o2.data(), d_o2, n * 2, hipMemcpyDeviceToHost));
+    float md = 0.f;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t a = (uint32_t)h_o1[i] << 16, b = (uint32_t)h_o2[i] << 16;
+        float fa, fb;
+        memcpy(&fa, &a, 4); memcpy(&fb, &b, 4);
+        const float d = fabsf(fa - fb);
+        if (!(d <= md)) md = d;  // NaN sticks
+    }
+    *max_diff = md; *ms_classic = ms[0] / iters; *ms_pc = ms[1] / iters;
+#ifdef HH_STAMP
+    {
+        unsigned long long stv[64];
+        HH_CHECK_HIP(hipMemcpy(stv, d_st, sizeof(stv), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 8; ++w) {
+            fprintf(stderr, "  wave %d (100 MHz ticks from its iteration start):", w);
+            for (int i = 1; i < 5; ++i) fprintf(stderr, " %lld", stv[w * 8 + i] ? (long long)(stv[w * 8 + i] - stv[w * 8]) : -1ll);
+            fprintf(stderr, "   start %+lld vs wave 0\n", (long long)(stv[w * 8] - stv[0]));
+        }
+    }
+#endif
+    hipFree(d_st);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(st);
+    hipFree(d_in); hipFree(d_o1); hipFree(d_o2); hipFree(d_w); hipFree(d_b);
+    return 0;
+}
+
 // Fused BasicBlock micro-benchmark; with a -DHH_STAMP build also returns s_memtime stamps of workgroup 0.
 extern "C" int hh_debug_bb_bench(int B, int H, int W, int iters, float *ms_per_launch, unsigned long long *stamps64)
 {

@@ -473,6 +473,8 @@ int hh_net::finalize()
         if (!p.loaded && !p.counter) { hh_set_error("hh_finalize: parameter never loaded: " + p.name); return 1; }
     HH_CHECK_HIP(conv_init());
     HH_CHECK_HIP(bb_fused_init());
+    HH_CHECK_HIP(bbpc_init());
+    bb32_pc = getenv("HH_BB32") && !strcmp(getenv("HH_BB32"), "pc");
     HH_CHECK_HIP(bb64_fused_init());
     HH_CHECK_HIP(bb128_fused_init());
 #ifdef HH_EXPERIMENTAL
@@ -855,6 +857,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
 #ifdef HH_EXPERIMENTAL
             else if (bb32_thin) HH_CHECK_HIP(bb_thin_launch(p, num_cus, s));
 #endif
+            else if (bb32_pc) HH_CHECK_HIP(bbpc_launch(p, num_cus, s));
             else HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
             break;
         }
