@@ -101,6 +101,9 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fused_kernel(const BBParams p)
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0) atomicMin(p.clk, wall_clock64());
 #endif
+#ifdef HH_STAMP  // in-kernel clock of workgroup 0: d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6)
+    if (p.stamps && blockIdx.x == 0 && tid == 0) { p.stamps[64] = __builtin_amdgcn_s_memtime(); p.stamps[65] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     const int wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
 
@@ -350,6 +353,9 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fused_kernel(const BBParams p)
     for (int q = 0; q < 2; ++q) store_rows(q);
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
+#endif
+#ifdef HH_STAMP
+    if (p.stamps && blockIdx.x == 0 && tid == 0) { p.stamps[66] = __builtin_amdgcn_s_memtime(); p.stamps[67] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 }
 

@@ -1,23 +1,31 @@
 // Fused 32-channel BasicBlock, producer / consumer form:   out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x)
-// -- /root/reference/src/keypoints/architectures/hrnet.py:108-124 -- in ONE kernel, like basicblock_fused.hip, but
-// organised around the LDS instead of around the tile:
+// -- /root/reference/src/keypoints/architectures/hrnet.py:108-124 -- in ONE kernel, like basicblock_fused.hip (the "tile
+// form", kept behind HH_BB32=tile), but organised around the LDS and the vector-instruction budget instead of around the tile:
 //
-//   basicblock_fused.hip reads 1.3 ds_read_b128 per MFMA (every wave re-reads its weight fragments for every tile and
-//   conv1 reads one pixel fragment per MFMA), which together with the 13-cycle ds_write_b128 keeps the LDS ~85 % busy
-//   and the matrix cores ~40 %.  Here
-//     * waves 0-3 only ever run conv1 and waves 4-7 only conv2, so each wave keeps ITS conv's 18 weight fragments in
-//       72 VGPRs for the life of the (persistent) workgroup: no weight reads at all;
-//     * a wave owns a band of rows, and a pixel fragment (one row, one kx shift, one k half) feeds the three output rows
-//       it is a tap of (ky = 0..2): 6 reads per 12 MFMAs in a 4-row band;
-//   = 0.45 ds_read_b128 per MFMA.  The two groups work one tile apart (conv1 of tile t+1 beside conv2 of tile t) with one
-//   workgroup barrier per tile; wave w and wave w+4 share a SIMD, so one's epilogue VALU / LDS / store work sits under
-//   the other's MFMAs.
+//   * waves 0-3 only ever run conv1 and waves 4-7 only conv2, so each wave keeps ITS conv's 18 weight fragments in 72 VGPRs
+//     for the life of the (persistent) workgroup: no weight reads (the tile form re-reads them for every tile);
+//   * a wave owns a band of rows, and a pixel fragment (one row, one kx shift, one k half) feeds the three output rows it is a
+//     tap of (ky = 0..2): 6 reads per 12 MFMAs in a 4-row band.  Together 0.45 ds_read_b128 per MFMA instead of 1.3;
+//   * the two groups work one tile apart (conv1 of tile t+1 beside conv2 of tile t) with ONE workgroup barrier per tile, and
+//     the two waves of a SIMD (w and w+4) run in antiphase inside it: the producer issues its MFMAs first and packs / writes
+//     the mid rows second; the consumer first packs / stores the tile of the iteration before (its accumulators survive the
+//     barrier) and then issues its MFMAs;
+//   * LDS fragment reads are asm statements with hand-counted waits (lds_read_async / lds_wait): left to the compiler the
+//     software pipeline collapses (it renames the rotating fragment registers and waits right behind the reads).
 //
 // Tile: 14x32 outputs, 16x34 mid pixels, 18x36 input patch; patch and mid tile are double buffered (157 KB of LDS), pixels
 // are 64 bytes (no padding): the 16-byte part index is XOR-swizzled by (x >> 2) & 3 (and by (row >> 1) & 3 in the
 // patch, whose rows are 38 pixels apart), which makes every ds_read_b128 below conflict-free, the column tile of the
 // two extra mid columns (lanes = 16 rows x 2 columns) included.
-// The residual is added in fp32 from global memory (the lines are L2-warm: the patch was fetched one tile earlier).
+// The residual enters as the accumulators' initial value (shift + x, fp32) from global memory: the lines are L2-warm, the
+// patch was fetched one tile earlier.
+//
+// Measured (tools/bb_compare.py, 1 s of back-to-back launches, B = 32): 128x128 26.9 us vs 27.4 us for the tile form, 256x256
+// 90 vs 94 us; in the forward 5.03 vs 5.12 ms (4 lanes), 5.75 vs 5.95 ms (one lane).  Halving the LDS reads bought this little
+// because neither form is bound by the LDS or by issue slots: with every load and store compiled out (-DBBPC_NOLOAD -DBBPC_NOSTORE
+// -DBBPC_NORES) the same instruction stream runs the 256x256 case in 65 us at an in-kernel clock of 2.40 GHz; with its 268 MB
+// of HBM traffic it takes 8 % more cycles and the chip holds only 1.9-2.0 GHz (d s_memtime / d s_memrealtime, -DHH_STAMP
+// build) -- the block is bound by what the chip can power: HBM streaming at ~3 TB/s beside ~0.85 PFLOP/s of MFMA.
 #include "kernels.h"
 
 #include <utility>
@@ -113,6 +121,10 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0) atomicMin(p.clk, wall_clock64());
 #endif
+#ifdef HH_STAMP  // in-kernel clock of workgroup 0: d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6)
+    if (p.stamps && blockIdx.x == 0 && tid == 0) { p.stamps[64] = __builtin_amdgcn_s_memtime(); p.stamps[65] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char *)smem;  // LDS byte address of smem[0], for the asm reads
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const bool producer = wave < 4;
@@ -248,10 +260,10 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
                 constexpr int s = decltype(sc)::value;
                 if constexpr (s >= NE) {
                     constexpr int c = (s - NE) / NR, i = (s - NE) % NR, kx = c >> 1, kk = c & 1;
-                    fb[buf] = lds_read_async<i * PRS * 64>(pcur + (pa0[kx][kk] ^ kb[i >> 1]));
+                    fb[buf] = lds_read_async<i * PRS * 64>(lds0 + pcur + (pa0[kx][kk] ^ kb[i >> 1]));
                 } else {
                     constexpr int tap = s >> 1, kk = s & 1, ky = tap / 3, kx = tap % 3;
-                    fb[buf] = lds_read_async<kx * 64>(ea[ky][kk]);
+                    fb[buf] = lds_read_async<kx * 64>(lds0 + ea[ky][kk]);
                 }
             };
             auto edge_out = [&]() {
@@ -405,11 +417,12 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
                                 }
                             }
                     }
+                    PSTAMP(2);
                     constexpr int NR = RC + 2, NS = 6 * NR;
                     u32x4 fb[NFBC];
                     auto ldb = [&](auto sc, int buf) {
                         constexpr int s = decltype(sc)::value, c = s / NR, i = s % NR, kx = c >> 1, kk = c & 1;
-                        fb[buf] = lds_read_async<i * MW * 64>(mcur + ma0[kx][kk]);
+                        fb[buf] = lds_read_async<i * MW * 64>(lds0 + mcur + ma0[kx][kk]);
                     };
                     static_for<RDC>([&](auto sc) { ldb(sc, decltype(sc)::value); });
                             static_for<NS>([&](auto sc) {
@@ -421,6 +434,9 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
                             pf_write(std::integral_constant<int, s - (NS - 12)>{}, pnext);
                             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                         }
+                        if constexpr (s == 2) PSTAMP(5);
+                        if constexpr (s == NS / 2) PSTAMP(6);
+                        if constexpr (s == 3 * NS / 4) PSTAMP(7);
                         lds_wait<(NS - 1 - s < RDC ? NS - 1 - s : RDC)>(fb[s % NFBC]);
                         constexpr int nm = (i == 0 || i == NR - 1) ? 1 : ((i == 1 || i == NR - 2) ? 2 : 3);
                         static_for<3>([&](auto kyc) {
@@ -445,6 +461,9 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
     }
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
+#endif
+#ifdef HH_STAMP
+    if (p.stamps && blockIdx.x == 0 && tid == 0) { p.stamps[66] = __builtin_amdgcn_s_memtime(); p.stamps[67] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 }
 

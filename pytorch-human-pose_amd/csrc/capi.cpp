@@ -600,8 +600,8 @@ extern "C" int hh_debug_bb_compare(int B, int H, int W, int iters, float *max_di
     p.in = d_in; p.in_cs = 32; p.out_cs = 32; p.w1 = d_w; p.w2 = d_w + 9 * 32 * 32; p.b1 = d_b; p.b2 = d_b + 32;
     p.B = B; p.H = H; p.W = W;
     unsigned long long *d_st = nullptr;
-    HH_CHECK_HIP(hipMalloc((void **)&d_st, 64 * 8));
-    HH_CHECK_HIP(hipMemset(d_st, 0, 64 * 8));
+    HH_CHECK_HIP(hipMalloc((void **)&d_st, 72 * 8));
+    HH_CHECK_HIP(hipMemset(d_st, 0, 72 * 8));
     p.stamps = d_st;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -622,6 +622,14 @@ extern "C" int hh_debug_bb_compare(int B, int H, int W, int iters, float *max_di
         HH_CHECK_HIP(hipEventRecord(e1, st));
         HH_CHECK_HIP(hipEventSynchronize(e1));
         HH_CHECK_HIP(hipEventElapsedTime(&ms[v], e0, e1));
+#ifdef HH_STAMP
+        {
+            unsigned long long c[4];
+            HH_CHECK_HIP(hipMemcpy(c, d_st + 64, sizeof(c), hipMemcpyDeviceToHost));
+            if (c[3] > c[1]) fprintf(stderr, "  %s: in-kernel clock of the last launch %.3f GHz (%lld core cycles in %.2f us)\n", v ? "producer/consumer" : "tile form",
+                                     (double)(c[2] - c[0]) / (double)(c[3] - c[1]) * 0.1, (long long)(c[2] - c[0]), (double)(c[3] - c[1]) * 0.01);
+        }
+#endif
     }
     HH_CHECK_HIP(hipMemcpy(h_o1.data(), d_o1, n * 2, hipMemcpyDeviceToHost));
     HH_CHECK_HIP(hipMemcpy(h_o2.data(), d_o2, n * 2, hipMemcpyDeviceToHost));
@@ -636,11 +644,11 @@ extern "C" int hh_debug_bb_compare(int B, int H, int W, int iters, float *max_di
     *max_diff = md; *ms_classic = ms[0] / iters; *ms_pc = ms[1] / iters;
 #ifdef HH_STAMP
     {
-        unsigned long long stv[64];
+        unsigned long long stv[72];
         HH_CHECK_HIP(hipMemcpy(stv, d_st, sizeof(stv), hipMemcpyDeviceToHost));
         for (int w = 0; w < 8; ++w) {
             fprintf(stderr, "  wave %d (100 MHz ticks from its iteration start):", w);
-            for (int i = 1; i < 5; ++i) fprintf(stderr, " %lld", stv[w * 8 + i] ? (long long)(stv[w * 8 + i] - stv[w * 8]) : -1ll);
+            for (int i = 1; i < 8; ++i) fprintf(stderr, " %lld", stv[w * 8 + i] ? (long long)(stv[w * 8 + i] - stv[w * 8]) : -1ll);
             fprintf(stderr, "   start %+lld vs wave 0\n", (long long)(stv[w * 8] - stv[0]));
         }
     }
@@ -669,7 +677,7 @@ extern "C" int hh_debug_bb_bench(int B, int H, int W, int iters, float *ms_per_l
     HH_CHECK_HIP(hipMalloc((void **)&d_out, n * 2));
     HH_CHECK_HIP(hipMalloc((void **)&d_w, h_w.size() * 2));
     HH_CHECK_HIP(hipMalloc((void **)&d_b, 32 * 4));
-    HH_CHECK_HIP(hipMalloc((void **)&d_st, 64 * 8));
+    HH_CHECK_HIP(hipMalloc((void **)&d_st, 72 * 8));
     HH_CHECK_HIP(hipMemcpy(d_in, h_in.data(), n * 2, hipMemcpyHostToDevice));
     HH_CHECK_HIP(hipMemcpy(d_w, h_w.data(), h_w.size() * 2, hipMemcpyHostToDevice));
     HH_CHECK_HIP(hipMemset(d_b, 0, 32 * 4));

@@ -474,7 +474,7 @@ int hh_net::finalize()
     HH_CHECK_HIP(conv_init());
     HH_CHECK_HIP(bb_fused_init());
     HH_CHECK_HIP(bbpc_init());
-    bb32_pc = getenv("HH_BB32") && !strcmp(getenv("HH_BB32"), "pc");
+    bb32_pc = !(getenv("HH_BB32") && !strcmp(getenv("HH_BB32"), "tile"));  // default: producer / consumer form; HH_BB32=tile: basicblock_fused.hip
     HH_CHECK_HIP(bb64_fused_init());
     HH_CHECK_HIP(bb128_fused_init());
 #ifdef HH_EXPERIMENTAL

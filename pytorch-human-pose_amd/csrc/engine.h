@@ -134,7 +134,7 @@ struct hh_net {
     std::vector<hipEvent_t> lane_events;
     size_t lane_events_used = 0;
     bool multi_lane = true;
-    bool bb32_pc = false;    // HH_BB32=pc: the producer / consumer form of the fused 32-channel block
+    bool bb32_pc = true;     // the producer / consumer form of the fused 32-channel block (HH_BB32=tile selects the tile form)
     bool bb32_thin = false;  // HH_BB32=thin: the half-CU variant of the fused 32-channel block (experiment switch)
     // fp8 path (dtype == HH_DTYPE_FP8)
     bool calibrated = false;      // activation scales set (hh_calibrate)

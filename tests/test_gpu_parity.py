@@ -103,6 +103,35 @@ def test_fused_128_channel_block_opt_in(pkg, net_golden):
         near(a, b)
 
 
+def test_fused_32_channel_block_both_forms(pkg, net_golden):
+    """The 32-channel BasicBlock has two fused kernels: basicblock_fused_pc.hip (producer / consumer waves, the default) and
+    basicblock_fused.hip (HH_BB32=tile).  Both meet the stated tolerance against the reference golden, differ from each other
+    only by bf16 rounding of different summation orders, and the stand-alone A/B entry agrees on ragged shapes."""
+    x = torch.from_numpy(pkg.synth.synth_images(2, 128, 128, 1)).to(DEV)
+    pc_net, _ = _net(pkg, 32, 1)
+    os.environ["HH_BB32"] = "tile"
+    try:
+        tile_net, _ = _net(pkg, 32, 1)
+    finally:
+        del os.environ["HH_BB32"]
+    for net in (pc_net, tile_net):
+        hms, tags = net(x)
+        _close(hms[0].cpu().numpy(), net_golden["w32_128/hm_q"], "hm_q")
+        _close(hms[1].cpu().numpy(), net_golden["w32_128/hm_h"], "hm_h")
+        _close(tags.cpu().numpy(), net_golden["w32_128/tags"], "tags")
+    a, b = pc_net.forward_raw(x), tile_net.forward_raw(x)
+    assert not torch.equal(a[0], b[0])  # two kernels really ran
+    for u, v in zip(a, b):
+        assert (u - v).abs().max().item() <= 4e-2 * v.abs().max().item() and (u - v).pow(2).mean().sqrt().item() <= 2e-2 * v.pow(2).mean().sqrt().item()
+    # one block, random input in +-[0.5, 4), weights +-[0.008, 0.03): outputs up to ~16, so one bf16 ulp is 0.0625
+    lib = pkg._lib.load()
+    import ctypes as C
+    for (B, H, W) in [(1, 14, 32), (2, 30, 44), (3, 61, 77), (2, 128, 128)]:
+        md, m0, m1 = C.c_float(), C.c_float(), C.c_float()
+        pkg._lib.check(lib.hh_debug_bb_compare(B, H, W, 1, C.byref(md), C.byref(m0), C.byref(m1)))
+        assert md.value <= 0.0625, (B, H, W, md.value)
+
+
 def test_forward_full_size_samples_and_batch_consistency(pkg, net_golden):
     net, _ = _net(pkg, 32, 0)
     x1 = torch.from_numpy(pkg.synth.synth_images(1, 512, 512, 7)).to(DEV)

@@ -156,6 +156,8 @@ for n in set(fetch) | set(write):
         traffic[key] = max(traffic.get(key, 0.0), round(total, -5))
     elif n.startswith("bb_fused_kernel"):
         traffic["bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)"] = round(total, -5)
+    elif n.startswith("bbpc_kernel"):
+        traffic["bbpc_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32, producer/consumer waves)"] = round(total, -5)
     elif n.startswith("bb64_fused_kernel"):
         traffic["bb64_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=64)"] = round(total, -5)
 DECODE = ("stage_average", "nms_tile_topk", "topk_merge", "match_kernel", "adjust_scores", "refine_", "tag_bounds")
