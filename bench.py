@@ -62,6 +62,10 @@ def collect_profile(pkg, net, peak=MFMA_BF16_DENSE_PEAK_TFLOPS):
         d["n"] += 1
         d["ms"] += ms.value
         d["kms"] += kms.value if kms.value > 0 else ms.value
+        ghz = C.c_double()
+        pkg._lib.check(lib.hh_profile_clock(net._h, i, C.byref(ghz)))
+        if ghz.value > 0:
+            d.setdefault("ghz", []).append(ghz.value)
         d["flops"] += flops.value
         d["bytes"] += nbytes.value
         # roofline time of this launch: max(FLOPs / MFMA peak, algorithmic bytes / HBM peak)
@@ -323,6 +327,8 @@ def main():
             for c, d in collect_profile(pkg, net, cfgd["peak"]).items():
                 if c in per_cfg:
                     per_cfg[c]["kms"] = d["kms"] * per_cfg[c]["n"] / d["n"]
+                    if d.get("ghz"):
+                        per_cfg[c]["ghz"] = d["ghz"]
             lib.hh_profile_enable(net._h, 0)
         # split of the step (not part of the timed region): forward alone / decode alone, graph replay
         net.use_graph = True
@@ -398,6 +404,10 @@ def main():
                 "hbm_frac": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "roofline_ceiling_tflops": round(d["flops"] / d["ceil_s"] / 1e12, 1),
                 "frac_of_ceiling": round(d["ceil_s"] / (d["ms"] * 1e-3), 4),
+                # the core clock workgroup 0 of these launches ran at (s_memtime / s_memrealtime deltas in the extra, stamped probe step): the
+                # chip holds it below its 2.4 GHz under this load, and `peak` is quoted at 2.4 GHz
+                "in_kernel_clock_ghz": round(sum(d["ghz"]) / len(d["ghz"]), 3) if d.get("ghz") else None,
+                "frac_of_peak_at_that_clock": round(achieved / (cfgd["peak"] * (sum(d["ghz"]) / len(d["ghz"])) / 2.4), 4) if d.get("ghz") else None,
                 "share_of_conv_time": round(d["ms"] / total_ms, 3),
                 "all_conv_tflops": round(sum(v["flops"] for v in per_cfg.values()) / (total_ms * 1e-3) / 1e12, 2),
             }

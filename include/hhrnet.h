@@ -106,6 +106,9 @@ double hh_forward_flops(const hh_net *net, int B, int H, int W);
 int hh_profile_enable(hh_net *net, int enable);
 int hh_profile_count(const hh_net *net);
 int hh_profile_get(hh_net *net, int index, int *cfg, double *flops, double *bytes, float *ms, float *kernel_ms, const char **layer);
+/* mode 2 only, kernels that stamp it (the fused 32-channel block): the core clock workgroup 0 of launch `index` ran at, from
+ * s_memtime / s_memrealtime deltas inside the kernel; 0 = not stamped.  Under load the chip holds this well below its 2.4 GHz. */
+int hh_profile_clock(hh_net *net, int index, double *ghz);
 int hh_conv_config(int cfg, int out[7]);
 
 /* Kernel micro-benchmark used by tools/conv_bench.py (not on the hot path): `iters` back-to-back launches of

@@ -60,6 +60,7 @@ def _sig(lib):
         "hh_profile_count": (i32, [vp]),
         "hh_profile_get": (i32, [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float),
                            C.POINTER(C.c_char_p)]),
+        "hh_profile_clock": (i32, [vp, i32, C.POINTER(C.c_double)]),
         "hh_conv_config": (i32, [i32, C.POINTER(C.c_int)]),
         "hh_debug_conv_bench": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp, i32, C.POINTER(C.c_float)]),
         "hh_debug_bb_bench": (i32, [i32, i32, i32, i32, C.POINTER(C.c_float), vp]),

@@ -120,6 +120,9 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
     const int tid = threadIdx.x;
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0) atomicMin(p.clk, wall_clock64());
+    // workgroup 0 also leaves its core-cycle and wall-tick counts: their ratio is the clock the chip held during this launch
+    const unsigned long long clk_c0 = p.clk && blockIdx.x == 0 ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long clk_r0 = p.clk && blockIdx.x == 0 ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
 #ifdef HH_STAMP  // in-kernel clock of workgroup 0: d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6)
     if (p.stamps && blockIdx.x == 0 && tid == 0) { p.stamps[64] = __builtin_amdgcn_s_memtime(); p.stamps[65] = __builtin_amdgcn_s_memrealtime(); }
@@ -461,6 +464,10 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
     }
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0) atomicMax(p.clk + 1, wall_clock64());
+    if (p.clk && blockIdx.x == 0 && tid == 0) {
+        p.clk[2] = __builtin_amdgcn_s_memtime() - clk_c0;
+        p.clk[3] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
 #endif
 #ifdef HH_STAMP
     if (p.stamps && blockIdx.x == 0 && tid == 0) { p.stamps[66] = __builtin_amdgcn_s_memtime(); p.stamps[67] = __builtin_amdgcn_s_memrealtime(); }

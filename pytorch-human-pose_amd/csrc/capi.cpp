@@ -136,8 +136,21 @@ int hh_profile_get(hh_net *net, int i, int *cfg, double *flops, double *bytes, f
     *kernel_ms = -1.f;
     if (r.slot >= 0 && net->prof_clk && net->d_clk && net->clk_khz > 0) {
         unsigned long long t[2];
-        HH_CHECK_HIP(hipMemcpy(t, net->d_clk + 2 * r.slot, 16, hipMemcpyDeviceToHost));
+        HH_CHECK_HIP(hipMemcpy(t, net->d_clk + 4 * r.slot, 16, hipMemcpyDeviceToHost));
         if (t[1] > t[0]) *kernel_ms = (float)((double)(t[1] - t[0]) / net->clk_khz);
+    }
+    return 0;
+}
+int hh_profile_clock(hh_net *net, int i, double *ghz)
+{
+    if (i < 0 || i >= (int)net->prof_used) { hh_set_error("hh_profile_clock: index out of range"); return 1; }
+    const ProfRecord &r = net->prof[i];
+    *ghz = 0.0;
+    if (r.slot >= 0 && net->prof_clk && net->d_clk && net->clk_khz > 0) {
+        unsigned long long t[2];
+        HH_CHECK_HIP(hipEventSynchronize(r.e1));
+        HH_CHECK_HIP(hipMemcpy(t, net->d_clk + 4 * r.slot + 2, 16, hipMemcpyDeviceToHost));
+        if (t[1]) *ghz = (double)t[0] / (double)t[1] * net->clk_khz * 1e-6;  // core cycles per wall tick x wall ticks per second
     }
     return 0;
 }

@@ -673,14 +673,14 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
     };
     if (prof_enabled && prof_used == 0) {  // first forward since hh_profile_enable: device-clock slots start as {~0, 0}
         if (!d_clk) {
-            HH_CHECK_HIP(hipMalloc((void **)&d_clk, HH_PROF_SLOTS * 16));
+            HH_CHECK_HIP(hipMalloc((void **)&d_clk, HH_PROF_SLOTS * 32));
             int dev = 0, khz = 0;
             HH_CHECK_HIP(hipGetDevice(&dev));
             HH_CHECK_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
             clk_khz = khz;
         }
-        std::vector<unsigned long long> init(HH_PROF_SLOTS * 2);
-        for (int i = 0; i < HH_PROF_SLOTS; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0; }
+        std::vector<unsigned long long> init(HH_PROF_SLOTS * 4, 0ull);  // {min start, max end, core cycles, 100 MHz ticks of workgroup 0}
+        for (int i = 0; i < HH_PROF_SLOTS; ++i) init[4 * i] = ~0ull;
         HH_CHECK_HIP(hipMemcpy(d_clk, init.data(), init.size() * 8, hipMemcpyHostToDevice));
     }
     int lanes_open = 1;  // lanes [0, lanes_open) have work that the caller's stream must wait for at the end
@@ -735,7 +735,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->flops = 2.0 * B * (H / 2) * (W / 2) * 27.0 * 64.0;
                 pr->bytes = (double)B * H * W * 3 * 4 + (double)B * (H / 2) * (W / 2) * 64 * 2 + 64 * 32 * 2;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
-                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 2 * pr->slot;
+                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 4 * pr->slot;
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
             }
             HH_CHECK_HIP(stem_conv_launch(p, s));
@@ -805,7 +805,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->bytes = 2.0 * p.npix * (64 + (op.in2 >= 0 ? 64 : 256) + 256 + (op.layer3 >= 0 ? 64 : 0)) +
                             2.0 * 64 * 256 * (1 + (op.in2 >= 0) + (op.layer3 >= 0));
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
-                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 2 * pr->slot;
+                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 4 * pr->slot;
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
             }
             HH_CHECK_HIP(junction_launch(p, num_cus, s));
@@ -847,7 +847,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 const double Cb = l1.cout;
                 pr->cfg = l1.cout == 128 ? HH_CFG_BB128_FUSED : l1.cout == 64 ? HH_CFG_BB64_FUSED : HH_CFG_BB_FUSED;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
-                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 2 * pr->slot;
+                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 4 * pr->slot;
                 pr->flops = 2.0 * 2.0 * B * p.H * p.W * Cb * Cb * 9.0;
                 pr->bytes = 2.0 * B * p.H * p.W * Cb * 2 + 2.0 * 2 * 9 * Cb * Cb;
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
@@ -925,7 +925,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->op = (int)(&op - ops.data());
                 pr->cfg = cfg;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
-                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 2 * pr->slot;
+                if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 4 * pr->slot;
                 pr->flops = 2.0 * B * p.Ho * p.Wo * (double)l.cin * l.cout * l.ks * l.ks * (p.nphase > 1 ? 4 : 1);
                 {
                     const double opix = (double)B * p.Ho * p.Wo * (p.nphase > 1 ? 4 : 1);

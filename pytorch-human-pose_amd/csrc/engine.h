@@ -125,7 +125,7 @@ struct hh_net {
     bool prof_clk = false;  // also stamp the device clock inside the kernels (their same-address atomics lengthen the launch by ~3-5 us)
     std::vector<ProfRecord> prof;
     size_t prof_used = 0;
-    unsigned long long *d_clk = nullptr;  // [HH_PROF_SLOTS][2]
+    unsigned long long *d_clk = nullptr;  // [HH_PROF_SLOTS][4]: {min start, max end} on the wall clock, {core cycles, wall ticks} of workgroup 0
     double clk_khz = 0;                   // hipDeviceAttributeWallClockRate
     // lanes 1..3: internal streams forked from / joined to the caller's stream (also inside hipGraph capture)
     hipStream_t lane_streams[4] = {nullptr, nullptr, nullptr, nullptr};

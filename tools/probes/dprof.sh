@@ -10,5 +10,5 @@ grep decode $out/dprof.log
 python3 -c "
 import csv,glob
 f=sorted(glob.glob('gpurun_out/dprof/**/*kernel_stats.csv',recursive=True))[-1]
-for r in list(csv.DictReader(open(f)))[:9]: print(r['Name'][:44], r['Calls'], round(float(r['AverageNs'])/1e3,1))
+for r in list(csv.DictReader(open(f)))[:12]: print(r['Name'][:44], r['Calls'], round(float(r['AverageNs'])/1e3,1))
 "
