@@ -43,6 +43,9 @@ MFMA_FP8_DENSE_PEAK_TFLOPS = 5000.0   # same table: "Peak FP8 MFMA ~5 PF dense"
 CONFIGS = {
     "w32_b32_512": dict(C=32, dtype="bf16", batch=32, size=512, peak=MFMA_BF16_DENSE_PEAK_TFLOPS,
                         metric="images/sec (fwd+decode) HigherHRNet-W32 512px", name="HigherHRNet-W32 inference bf16"),
+    # (not a BASELINE.json line: the fp8 workload's net, batch and size on the bf16 path, for the fp8 / bf16 ratio on one box)
+    "bf16_w48_b64_640": dict(C=48, dtype="bf16", batch=64, size=640, peak=MFMA_BF16_DENSE_PEAK_TFLOPS,
+                             metric="images/sec (fwd+decode) HigherHRNet-W48 bf16 640px", name="HigherHRNet-W48 inference bf16"),
     "fp8_w48_b64_640": dict(C=48, dtype="fp8", batch=64, size=640, peak=MFMA_FP8_DENSE_PEAK_TFLOPS,
                             metric="images/sec (fwd+decode) HigherHRNet-W48 fp8 640px", name="HigherHRNet-W48 inference fp8 (e4m3 MFMA conv path)"),
 }
@@ -217,7 +220,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default: the config's)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="w32_b32_512",
-                    help="BASELINE.json workload: w32_b32_512 = configs[1] (headline), fp8_w48_b64_640 = configs[4]")
+                    help="BASELINE.json workload: w32_b32_512 = configs[1] (headline), fp8_w48_b64_640 = configs[4]; bf16_w48_b64_640 = that workload on the bf16 path")
     ap.add_argument("--people", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch probe steps behind the timed loop")

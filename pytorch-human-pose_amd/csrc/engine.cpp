@@ -204,6 +204,8 @@ struct Builder {
         // alternations: 5512 / 5511 img/s without it, 5451 / 5432 with it in stage 2 only, 5395 / 5415 everywhere.  Its 150 KB
         // workgroups take whole CUs, while the layer-by-layer launches (64 KB workgroups) share CUs with each other and with
         // the 256-channel branch.  HH_BB128=all | stage2 enables it (serial execution, experiments).
+        // (switches are read when the plan is built, i.e. in hh_create)
+        n.bb32_pc = !(getenv("HH_BB32") && !strcmp(getenv("HH_BB32"), "tile"));  // default: producer / consumer form; HH_BB32=tile: basicblock_fused.hip
         const char *e128 = getenv("HH_BB128");
         const bool bb128 = C == 128 && e128 && (!strcmp(e128, "all") || (!strcmp(e128, "stage2") && nscales == 3));
         for (int u = 0; u < 4; ++u) {
@@ -474,7 +476,6 @@ int hh_net::finalize()
     HH_CHECK_HIP(conv_init());
     HH_CHECK_HIP(bb_fused_init());
     HH_CHECK_HIP(bbpc_init());
-    bb32_pc = !(getenv("HH_BB32") && !strcmp(getenv("HH_BB32"), "tile"));  // default: producer / consumer form; HH_BB32=tile: basicblock_fused.hip
     HH_CHECK_HIP(bb64_fused_init());
     HH_CHECK_HIP(bb128_fused_init());
 #ifdef HH_EXPERIMENTAL
