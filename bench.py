@@ -369,16 +369,20 @@ def main():
         if per_cfg:
             dom = max(per_cfg, key=lambda c: per_cfg[c]["ms"])
             d = per_cfg[dom]
-            cfgv = (C.c_int * 7)()
-            kname = {100: "bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)" if os.environ.get("HH_BB32") == "tile" else
+            def kernel_name(c):
+                nm = names.get(c, str(c))
+                cv = (C.c_int * 7)()
+                if lib.hh_conv_config(c, cv) == 0:
+                    nm = ("conv_fp8_kernel" if c >= 1000 else "conv_mfma_kernel") + "<KS=%d,S=%d,KC=%d,NT=%d,WC=%d,PT=%d,TW=%d>" % tuple(cv)
+                return nm
+            names = {100: "bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)" if os.environ.get("HH_BB32") == "tile" else
                           "bbpc_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32, producer/consumer waves)",
                      105: "bb_fp8_kernel (fused e4m3 BasicBlock: conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU)",
                      104: "bb128_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=128)",
                      103: "bb64_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=64)",
                      102: "stem_conv_kernel (fp32 NCHW -> conv3x3 s2 3->64 + BN + ReLU -> bf16 NHWC)",
-                     101: "junction_kernel (stage-0 conv3 1x1 [+downsample] + residual + ReLU + next conv1 1x1 + ReLU)"}.get(dom, str(dom))
-            if lib.hh_conv_config(dom, cfgv) == 0:
-                kname = ("conv_fp8_kernel" if dom >= 1000 else "conv_mfma_kernel") + "<KS=%d,S=%d,KC=%d,NT=%d,WC=%d,PT=%d,TW=%d>" % tuple(cfgv)
+                     101: "junction_kernel (stage-0 conv3 1x1 [+downsample] + residual + ReLU + next conv1 1x1 + ReLU)"}
+            kname = kernel_name(dom)
             # Per-launch duration = the dispatch packet's begin .. end timestamps, delivered through the start / stop events of
             # hipExtLaunchKernelGGL on the launch stream: the quantity rocprofv3's kernel trace reports (serial pass in
             # profiles/rNN_bench_kernel_stats.csv).  The kernel's own first-workgroup-start .. last-workgroup-end on the device
@@ -412,6 +416,10 @@ def main():
                 "in_kernel_clock_ghz": round(sum(d["ghz"]) / len(d["ghz"]), 3) if d.get("ghz") else None,
                 "frac_of_peak_at_that_clock": round(achieved / (cfgd["peak"] * (sum(d["ghz"]) / len(d["ghz"])) / 2.4), 4) if d.get("ghz") else None,
                 "share_of_conv_time": round(d["ms"] / total_ms, 3),
+                # the next kernels by summed time (the first two are close: which one leads differs from box to box)
+                "runners_up": [{"kernel": kernel_name(c), "launches": v["n"], "avg_launch_us": round(v["ms"] / v["n"] * 1e3, 2),
+                                "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / cfgd["peak"], 4), "share_of_conv_time": round(v["ms"] / total_ms, 3)}
+                               for c, v in sorted(per_cfg.items(), key=lambda kv: -kv[1]["ms"])[1:4]],
                 "all_conv_tflops": round(sum(v["flops"] for v in per_cfg.values()) / (total_ms * 1e-3) / 1e12, 2),
             }
         # decode half against the HBM roofline: compulsory bytes (read every network output once) over the
