@@ -18,12 +18,21 @@ ob = (torch.empty(16, 34, 128, 128, device="cuda"), torch.empty(16, 17, 256, 256
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 def run32():
     with torch.cuda.stream(s1): n1.forward_raw(x, o32)
+def runseq16():  # two half batches one after the other on one stream: do the smaller tensors stay in the 256 MB Infinity Cache?
+    with torch.cuda.stream(s1):
+        n1.forward_raw(xa, oa)
+        n1.forward_raw(xb, ob)
+x8 = [x[i * 8:(i + 1) * 8].contiguous() for i in range(4)]
+o8 = [(torch.empty(8, 34, 128, 128, device="cuda"), torch.empty(8, 17, 256, 256, device="cuda")) for _ in range(4)]
+def runseq8():
+    with torch.cuda.stream(s1):
+        for i in range(4): n1.forward_raw(x8[i], o8[i])
 def run2x16():
     with torch.cuda.stream(s1): n1.forward_raw(xa, oa)
     with torch.cuda.stream(s2): n2.forward_raw(xb, ob)
 for lanes in (1, 0):
     lib.hh_set_multi_lane(n1._h, lanes); lib.hh_set_multi_lane(n2._h, lanes)
-    for name, fn in (("1 x B32", run32), ("2 x B16 concurrent", run2x16)):
+    for name, fn in (("1 x B32", run32), ("2 x B16 concurrent", run2x16), ("2 x B16 sequential", runseq16), ("4 x B8 sequential", runseq8)):
         for _ in range(5): fn()
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(20): fn()
