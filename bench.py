@@ -381,6 +381,7 @@ def main():
                      104: "bb128_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=128)",
                      103: "bb64_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=64)",
                      102: "stem_conv_kernel (fp32 NCHW -> conv3x3 s2 3->64 + BN + ReLU -> bf16 NHWC)",
+                     106: "stem_fused_kernel (fp32 NCHW -> conv3x3 s2 3->64 + BN + ReLU -> conv3x3 s2 64->64 + BN + ReLU -> bf16 NHWC)",
                      101: "junction_kernel (stage-0 conv3 1x1 [+downsample] + residual + ReLU + next conv1 1x1 + ReLU)"}
             kname = kernel_name(dom)
             # Per-launch duration = the dispatch packet's begin .. end timestamps, delivered through the start / stop events of

@@ -243,14 +243,21 @@ struct Builder {
         const int w[4] = {C, 2 * C, 4 * C, 8 * C};
         const std::string bb = "backbone";
         // stem (hrnet.py:354-358,378-384)
-        const int S1 = T(64, 1), X = T(64, 2);
+        // bf16: both stem convolutions in ONE kernel (stem_fused.hip), the half-resolution intermediate never leaves the CU
+        // (HH_NO_STEM_FUSED=1 and the fp8 path: two launches through the tensor S1)
+        const bool stem_fused = n.dtype != 2 && !getenv("HH_NO_STEM_FUSED");
+        const int S1 = stem_fused ? -1 : T(64, 1), X = T(64, 2);
         {   // conv1 reads the fp32 NCHW images itself (stem_conv.hip): no layout pass, no padded input channels
             Op o;
-            o.kind = OP_STEM; o.layer = L(bb + ".conv1", bb + ".bn1", 3, 64, 3, 2); o.out = S1;
+            o.kind = OP_STEM; o.layer = L(bb + ".conv1", bb + ".bn1", 3, 64, 3, 2); o.out = stem_fused ? X : S1;
             n.layers[o.layer].stem = true;
+            if (stem_fused) {
+                o.layer2 = L(bb + ".conv2", bb + ".bn2", 64, 64, 3, 2);
+                n.layers[o.layer2].stem2 = true;
+            }
             n.ops.push_back(o);
         }
-        conv(L(bb + ".conv2", bb + ".bn2", 64, 64, 3, 2), S1, X, 1);
+        if (!stem_fused) conv(L(bb + ".conv2", bb + ".bn2", 64, 64, 3, 2), S1, X, 1);
         tap("stem#0", X, 64);
 
         // stage 0: four Bottlenecks on one scale (hrnet.py:29-74), then the 256->C / 256->2C transition
@@ -475,6 +482,7 @@ int hh_net::finalize()
         if (!p.loaded && !p.counter) { hh_set_error("hh_finalize: parameter never loaded: " + p.name); return 1; }
     HH_CHECK_HIP(conv_init());
     HH_CHECK_HIP(bb_fused_init());
+    HH_CHECK_HIP(stem_fused_init());
     HH_CHECK_HIP(bbpc_init());
     HH_CHECK_HIP(bb64_fused_init());
     HH_CHECK_HIP(bb128_fused_init());
@@ -518,6 +526,7 @@ int hh_net::finalize()
         if (dtype == 2) continue;  // e4m3 weights: finalize_fp8() below
         const int cin_pad0 = round_up(l.cin, 16), coutp = round_up(l.cout, 32);
         if (l.bb128) { l.KC = 16; l.NT = 4; }  // basicblock_fused_c128.hip: [chunk of 16 cin][tap][2][128 couts][8]
+        else if (l.stem2) { l.KC = 64; l.NT = 2; }  // stem_fused.hip: [tap][8][64 couts][8]
         else if (hh_family_pick(l.ks, l.stride, cin_pad0, coutp, &l.KC, &l.NT)) {
             hh_set_error("no kernel family for conv " + l.conv);
             return 1;
@@ -662,6 +671,11 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         }
     }
     hipStream_t L[4] = {s0, multi ? lane_streams[1] : s0, multi ? lane_streams[2] : s0, multi ? lane_streams[3] : s0};
+    if (multi && getenv("HH_LANE_MAP")) {  // experiment: several lanes on one stream, e.g. 0012 = branches 0 and 1 share the caller's stream
+        const char *m = getenv("HH_LANE_MAP");
+        hipStream_t all[4] = {s0, lane_streams[1], lane_streams[2], lane_streams[3]};
+        for (int l = 0; l < 4 && m[l]; ++l) L[l] = all[(m[l] - '0') & 3];
+    }
     lane_events_used = 0;
     auto next_event = [&](hipEvent_t *e) -> int {
         if (lane_events_used == lane_events.size()) {
@@ -714,6 +728,32 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         }
         case OP_STEM: {
             const ConvLayer &l = layers[op.layer];
+            if (op.layer2 >= 0) {  // both stem convolutions in one kernel
+                const ConvLayer &l2 = layers[op.layer2];
+                StemFusedParams q{};
+                q.images = images; q.w1 = l.d_w; q.b1 = l.d_bias; q.w2 = l2.d_w; q.b2 = l2.d_bias;
+                q.out = tensors[op.out].ptr; q.out_cs = tensors[op.out].C;
+                q.B = B; q.H = H; q.W = W;
+                if (!stem_fused_supported(q)) { hh_set_error("hh_forward: the fused stem needs H, W multiples of 4 and 32-bit tensor offsets (HH_NO_STEM_FUSED=1)"); return 1; }
+                if (prof_enabled) {
+                    if (prof_used == prof.size()) {
+                        ProfRecord r{};
+                        HH_CHECK_HIP(hipEventCreate(&r.e0));
+                        HH_CHECK_HIP(hipEventCreate(&r.e1));
+                        prof.push_back(r);
+                    }
+                    ProfRecord *pr = &prof[prof_used++];
+                    pr->op = (int)(&op - ops.data());
+                    pr->cfg = HH_CFG_STEM_FUSED;
+                    pr->flops = 2.0 * B * (H / 2) * (W / 2) * 27.0 * 64.0 + 2.0 * B * (H / 4) * (W / 4) * 576.0 * 64.0;
+                    pr->bytes = (double)B * H * W * 3 * 4 + (double)B * (H / 4) * (W / 4) * 64 * 2 + 64 * 32 * 2 + 73728;
+                    pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
+                    if (pr->slot >= 0 && prof_clk) q.clk = d_clk + 4 * pr->slot;
+                    hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};
+                }
+                HH_CHECK_HIP(stem_fused_launch(q, num_cus, s));
+                break;
+            }
             StemParams p{};
             p.images = images; p.w = l.d_w; p.bias = l.d_bias;
             p.out = tensors[op.out].ptr; p.out_cs = tensors[op.out].C;
@@ -1065,7 +1105,11 @@ double hh_net::flops(int B, int H, int W) const
             macs += 2.0 * (double)(H >> ti.shift) * (W >> ti.shift) * Cb * Cb * 9.0;
             continue;
         }
-        if (op.kind == OP_STEM) { macs += (double)(H / 2) * (W / 2) * 27.0 * 64.0; continue; }
+        if (op.kind == OP_STEM) {
+            macs += (double)(H / 2) * (W / 2) * 27.0 * 64.0;
+            if (op.layer2 >= 0) macs += (double)(H / 4) * (W / 4) * 576.0 * 64.0;  // conv2 rides in the same launch
+            continue;
+        }
         if (op.kind == OP_JUNC) {
             const TensorDesc &ti = tensors[op.in];
             macs += (double)(H >> ti.shift) * (W >> ti.shift) * 64.0 * 256.0 * (1 + (op.in2 >= 0) + (op.layer3 >= 0));

@@ -32,6 +32,7 @@ struct ConvLayer {
     std::string conv, bn, bias;  // state-dict prefixes ("" = absent)
     int cin = 0, cout = 0, ks = 1, stride = 1;
     bool transposed = false;
+    bool stem2 = false; // second stem conv inside stem_fused.hip: packed [tap][cin/8][64 couts][8]
     bool stem = false;  // first conv of the net: packed for stem_conv.hip (K = 27 taps padded to 32)
     bool bb128 = false; // conv of a fused 128-channel BasicBlock: packed with 16-channel chunks over all 128 couts
     int py = 0, px = 0;  // phase of the transposed conv this entry implements (-1: all four, packed back to back)

@@ -200,6 +200,21 @@ struct StemParams {
 };
 #define HH_CFG_STEM 102  // pseudo instantiation index used by the profiler
 hipError_t stem_conv_launch(const StemParams &p, hipStream_t s);
+// Both stem convolutions in one kernel (stem_fused.hip): conv3x3 s2 3->64 + BN + ReLU -> conv3x3 s2 64->64 + BN + ReLU.
+struct StemFusedParams {
+    const float *images;      // [B,3,H,W], H and W multiples of 4
+    const bf16_raw *w1;       // conv1 as StemParams::w
+    const float *b1;          // [64]
+    const bf16_raw *w2;       // conv2 packed [tap 9][cin/8 8][64 couts][8] (hh_pack_weights with KC = 64, COUT_T = 64), BN scale folded
+    const float *b2;          // [64]
+    bf16_raw *out; int out_cs;  // [B,H/4,W/4,out_cs], channels 0..63
+    int B, H, W;
+    unsigned long long *clk;  // optional device-clock probe
+};
+#define HH_CFG_STEM_FUSED 106
+hipError_t stem_fused_init();
+bool stem_fused_supported(const StemFusedParams &p);
+hipError_t stem_fused_launch(const StemFusedParams &p, int num_cus, hipStream_t s);
 
 
 // out[b,y,x,c] = act(base[b,y,x,c] + sum_j up_j[b, y>>sh_j, x>>sh_j, c]),  c in [0,C)
