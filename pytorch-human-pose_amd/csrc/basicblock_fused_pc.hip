@@ -479,12 +479,18 @@ hipError_t bbpc_init()
     return hipFuncSetAttribute(reinterpret_cast<const void *>(bbpc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 }
 
+// 32-bit buffer offsets: both tensors must stay below 2 GB (the engine falls back to the tile form otherwise)
+bool bbpc_supported(const BBParams &p)
+{
+    return (size_t)p.B * p.H * p.W * (size_t)(p.in_cs > p.out_cs ? p.in_cs : p.out_cs) * 2 < 0x7fffffffull;
+}
+
 hipError_t bbpc_launch(BBParams p, int num_cus, hipStream_t s)
 {
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
-    if ((size_t)p.B * p.H * p.W * (size_t)(p.in_cs > p.out_cs ? p.in_cs : p.out_cs) * 2 >= 0x7fffffffull) return hipErrorInvalidValue;  // 32-bit buffer offsets
+    if (!bbpc_supported(p)) return hipErrorInvalidValue;
     const int grid = p.ntiles < num_cus ? p.ntiles : num_cus;
     HH_LAUNCH(bbpc_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, s, p);
     return hipGetLastError();

@@ -734,7 +734,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 q.images = images; q.w1 = l.d_w; q.b1 = l.d_bias; q.w2 = l2.d_w; q.b2 = l2.d_bias;
                 q.out = tensors[op.out].ptr; q.out_cs = tensors[op.out].C;
                 q.B = B; q.H = H; q.W = W;
-                if (!stem_fused_supported(q)) { hh_set_error("hh_forward: the fused stem needs H, W multiples of 4 and 32-bit tensor offsets (HH_NO_STEM_FUSED=1)"); return 1; }
+                if (!stem_fused_supported(q)) { hh_set_error("hh_forward: the fused stem needs H, W multiples of 4 and images below 2 GB (HH_NO_STEM_FUSED=1)"); return 1; }
                 if (prof_enabled) {
                     if (prof_used == prof.size()) {
                         ProfRecord r{};
@@ -898,7 +898,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
 #ifdef HH_EXPERIMENTAL
             else if (bb32_thin) HH_CHECK_HIP(bb_thin_launch(p, num_cus, s));
 #endif
-            else if (bb32_pc) HH_CHECK_HIP(bbpc_launch(p, num_cus, s));
+            else if (bb32_pc && bbpc_supported(p)) HH_CHECK_HIP(bbpc_launch(p, num_cus, s));
             else HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
             break;
         }

@@ -155,6 +155,7 @@ hipError_t bb_fused_init();
 hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s);
 // producer / consumer form of the same block (basicblock_fused_pc.hip): weights resident in registers, row-band fragment reuse
 hipError_t bbpc_init();
+bool bbpc_supported(const BBParams &p);
 hipError_t bbpc_launch(BBParams p, int num_cus, hipStream_t s);
 // the same block for the 64-channel branch (basicblock_fused_c64.hip): weights packed KS=3,S=1,KC=32,NT=2 ([chunk][tap][4][64][8])
 // "thin" variant of the 32-channel block (experimental/basicblock_fused_thin.hip, EXPERIMENTAL=1 builds only): half a CU per

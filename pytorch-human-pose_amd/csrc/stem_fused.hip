@@ -93,9 +93,8 @@ __global__ __launch_bounds__(256, 1) void stem_fused_kernel(const StemFusedParam
     const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char *)smem;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int H1 = p.H >> 1, W1 = p.W >> 1, H2 = p.H >> 2, W2 = p.W >> 2;
-    const size_t img_bytes = (size_t)p.B * 3 * p.H * p.W * 4, out_bytes = (((size_t)p.B * H2 * W2 - 1) * p.out_cs + 64) * 2;
-    const auto rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.images), 0, (int)img_bytes, 0x00020000);
-    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
+    // one buffer descriptor per IMAGE (32-bit offsets inside it): no limit on the batch
+    const size_t img_elems = (size_t)3 * p.H * p.W, out_elems = (size_t)H2 * W2 * p.out_cs;
     constexpr unsigned OOB = 0x80000000u;
 
     // ---- weights: conv1's four A fragments [cout tile][k-step] as stem_conv.hip, conv2's 36 fragments of this wave's cout tile
@@ -140,6 +139,7 @@ __global__ __launch_bounds__(256, 1) void stem_fused_kernel(const StemFusedParam
     auto patch_load = [&](int t) {
         const bool on = t < ntiles;
         const Geom g = geom(on ? t : 0);
+        const auto rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.images + (size_t)g.b * img_elems), 0, (int)(img_elems * 4), 0x00020000);
         const int iy0 = 4 * g.oy0 - 3, ix0 = 4 * g.ox0 - 3;
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 1) void stem_fused_kernel(const StemFusedParam
             const int c = i / PLANE, rem = i - c * PLANE, py = rem / PCW, px = rem - py * PCW;
             const int iy = iy0 + py, ix = ix0 + px;
             const bool ok = on & (i < NVAL) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-            const unsigned voff = ok ? (unsigned)((((g.b * 3 + c) * p.H + iy) * p.W + ix) * 4) : OOB;  // outside: 0 = conv1's padding
+            const unsigned voff = ok ? (unsigned)(((c * p.H + iy) * p.W + ix) * 4) : OOB;  // outside: 0 = conv1's padding
             pv[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, (int)voff, 0, 0));
         }
     };
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256, 1) void stem_fused_kernel(const StemFusedParam
             pack_rows16(acc, o);
             const int oy = g.oy0 + row2, ox = g.ox0 + r;
             const bool ok = (oy < H2) & (ox < W2);
-            const unsigned voff = ok ? (unsigned)((((g.b * H2 + oy) * W2 + ox) * p.out_cs + ct2 * 32 + 8 * h) * 2) : OOB;
+            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)g.b * out_elems, 0, (int)(out_elems * 2), 0x00020000);
+            const unsigned voff = ok ? (unsigned)(((oy * W2 + ox) * p.out_cs + ct2 * 32 + 8 * h) * 2) : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(o[0], rs_out, (int)voff, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(o[1], rs_out, (int)voff, 32, 0);
         }
@@ -262,8 +263,7 @@ hipError_t stem_fused_init()
 
 bool stem_fused_supported(const StemFusedParams &p)
 {
-    return p.H % 4 == 0 && p.W % 4 == 0 && (size_t)p.B * 3 * p.H * p.W * 4 < 0x7fffffffull &&
-           (size_t)p.B * (p.H / 4) * (p.W / 4) * p.out_cs * 2 < 0x7fffffffull;
+    return p.H % 4 == 0 && p.W % 4 == 0 && (size_t)3 * p.H * p.W * 4 < 0x7fffffffull && (size_t)(p.H / 4) * (p.W / 4) * p.out_cs * 2 < 0x7fffffffull;
 }
 
 hipError_t stem_fused_launch(const StemFusedParams &p, int num_cus, hipStream_t s)

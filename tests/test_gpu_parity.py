@@ -132,6 +132,27 @@ def test_fused_32_channel_block_both_forms(pkg, net_golden):
         assert md.value <= 0.0625, (B, H, W, md.value)
 
 
+def test_fused_stem_matches_two_launches(pkg, net_golden):
+    """stem_fused.hip (both stem convs in one kernel, the default) against stem_conv.hip + a conv launch (HH_NO_STEM_FUSED=1): the
+    stem tap and the outputs meet the golden tolerance either way, on a ragged batch / shape too the two paths agree to bf16 noise."""
+    os.environ["HH_NO_STEM_FUSED"] = "1"
+    try:
+        two, _ = _net(pkg, 32, 1)
+    finally:
+        del os.environ["HH_NO_STEM_FUSED"]
+    one, _ = _net(pkg, 32, 1)
+    x = torch.from_numpy(pkg.synth.synth_images(2, 128, 128, 1)).to(DEV)
+    for net in (one, two):
+        hms, tags = net(x)
+        _close(hms[0].cpu().numpy(), net_golden["w32_128/hm_q"], "hm_q")
+        _close(hms[1].cpu().numpy(), net_golden["w32_128/hm_h"], "hm_h")
+    for shape in ((3, 96, 160), (1, 32, 64), (5, 64, 32)):
+        x2 = torch.from_numpy(pkg.synth.synth_images(*shape, 2)).to(DEV)
+        a, b = one.forward_raw(x2), two.forward_raw(x2)
+        for u, v in zip(a, b):
+            assert (u - v).abs().max().item() <= 4e-2 * v.abs().max().item() and (u - v).pow(2).mean().sqrt().item() <= 2e-2 * v.pow(2).mean().sqrt().item(), shape
+
+
 def test_forward_full_size_samples_and_batch_consistency(pkg, net_golden):
     net, _ = _net(pkg, 32, 0)
     x1 = torch.from_numpy(pkg.synth.synth_images(1, 512, 512, 7)).to(DEV)
