@@ -178,10 +178,7 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
         }
         float tmax = -INFINITY;  // the largest half-res value any pixel of the tile or its halo interpolates
 #pragma unroll
-        for (int t = 0; t < NR; ++t) {
-            if (wv + 4 * t < PR) hrow[wv + 4 * t][lane] = __builtin_fmaf(ga[t], wxa, gb[t] * wxb);
-            tmax = fmaxf(tmax, fmaxf(ga[t], gb[t]));
-        }
+        for (int t = 0; t < NR; ++t) tmax = fmaxf(tmax, fmaxf(ga[t], gb[t]));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
         if (lane == 0) smax[wv] = tmax;
@@ -189,28 +186,26 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
         NMS_STAMP(1);
         tmax = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
         if (tmax + 4e-7f * fabsf(tmax) <= skip_thr) {
-            // Inactive tile: every full-resolution value in it is a convex combination of half-res values <= tmax (plus a few
-            // ulps of rounding, covered by the slack), so no pixel can pass det_thr and nothing this tile could emit survives
-            // match_by_tag's score filter (grouping.py:98-102).  It emits no candidates; the refine kernel still gets an upper
-            // bound of every 4x4 cell: the maximum of the horizontally interpolated rows the cell's pixels are built from.
+            // Inactive tile (three of four at 10 people per image): every full-resolution value in it is a convex combination of
+            // half-res values <= tmax (plus a few ulps of rounding, covered by the slack), so no pixel can pass det_thr and nothing
+            // this tile could emit survives match_by_tag's score filter (grouping.py:98-102).  It emits no candidates, and the
+            // refine kernel gets ONE upper bound for all its 4x4 cells, the tile's: such a cell is only ever looked at by a scan
+            // whose best value so far is below det_thr, and this path -- two loads per row, a maximum, 225 stores -- is what most
+            // workgroups of the launch run (per-cell bounds from the interpolated rows cost it a third more).
             if (tid < M) cand_key[((((size_t)b * src.K + k) * ntile) + tile) * M + tid] = 0ull;
             if (tid < (TS / 4) * (TS / 4)) {
                 const int cy = tid / (TS / 4), cx = tid % (TS / 4);
                 const int Y = y0 + 4 * cy, X = x0 + 4 * cx;
-                if (Y < src.H && X < src.W) {
-                    float m = -INFINITY;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int rr = min(max(pry + 2 * cy + a, 0), PR - 1);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) m = fmaxf(m, hrow[rr][2 + 4 * cx + c]);
-                    }
+                if (Y < src.H && X < src.W)
                     reinterpret_cast<unsigned short *>(cellmax)[(((size_t)b * src.K + k) * (src.H >> 2) + (Y >> 2)) * (src.W >> 2) + (X >> 2)] =
-                        bf16_ceil(m + 4e-7f * fabsf(m));
-                }
+                        bf16_ceil(tmax + 4e-7f * fabsf(tmax));
             }
             return;
         }
+#pragma unroll
+        for (int t = 0; t < NR; ++t)
+            if (wv + 4 * t < PR) hrow[wv + 4 * t][lane] = __builtin_fmaf(ga[t], wxa, gb[t] * wxb);
+        lds_barrier();
         const bool xin = X >= 0 && X < src.W;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
