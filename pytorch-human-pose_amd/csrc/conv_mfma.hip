@@ -144,10 +144,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     // ---- register staging.  load_unit(j, chunk) issues the j-th 16-byte load of a chunk (patch units first, then
     //      weight units) and never looks at the result, so no s_waitcnt lands next to it.
     u32x4 preg[NPL], wreg[NWL];
+    // element offset of chunk `chunk` from the chunk-0 pointers (wave-uniform): its channels, and for a conv over several
+    // concatenated inputs the distance to the tensor the chunk lives in
+    auto chunk_off = [&](int chunk) -> ptrdiff_t {
+        if (p.nch0 == 0 || chunk < p.nch0) return (ptrdiff_t)chunk * KC;
+        if (chunk < p.nch0 + p.nch1) return p.src_delta1 + (ptrdiff_t)(chunk - p.nch0) * KC;
+        return p.src_delta2 + (ptrdiff_t)(chunk - p.nch0 - p.nch1) * KC;
+    };
     auto load_unit = [&](auto jc, int chunk) {
         constexpr int j = decltype(jc)::value;
         if constexpr (j < NPL) {
-            preg[j] = *reinterpret_cast<const u32x4 *>(psrc[j] + ((pmask >> j) & 1u ? chunk * KC : 0));
+            preg[j] = *reinterpret_cast<const u32x4 *>(psrc[j] + ((pmask >> j) & 1u ? chunk_off(chunk) : 0));
         } else if constexpr (j < NL) {
             constexpr int i = j - NPL;
             const int u = tid + 256 * i;

@@ -337,6 +337,36 @@ struct Builder {
                         up.up[up.nup] = u; up.up_shift[up.nup] = j - i; ++up.nup;
                     }
                     if (up.nup) { n.ops.push_back(up); cur = OUT; }
+                    // high -> low, two or more sources (bf16): the LAST stride-2 conv of every chain reads at the resolution above the
+                    // output's, so the sum of those convs is one conv over the concatenated channels -- one launch instead of i
+                    // dependent ones on the lane that already has the longest chain.  Its inputs must share a pixel stride: chain
+                    // intermediates are allocated with the stride of branch i-1.  (HH_NO_FUSION_MERGE=1: one launch per source)
+                    if (i >= 2 && n.dtype != 2 && !getenv("HH_NO_FUSION_MERGE")) {
+                        int srcs[3] = {-1, -1, -1};
+                        ConvLayer ml;
+                        ml.cout = w[i]; ml.ks = 3; ml.stride = 2; ml.cin = 0;
+                        for (int j = i - 1; j >= 0; --j) {  // source order: branch i-1 itself first, then the chains
+                            const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
+                            int tin = x[j];
+                            for (int k = 0; k < i - j - 1; ++k) {
+                                const bool last_tmp = k == i - j - 2;
+                                const int tmp = T(last_tmp ? w[i - 1] : w[j], 2 + j + k + 1);  // (stride of branch i-1 for the merged conv's inputs)
+                                cb(lp + "." + std::to_string(k), "0", "1", w[j], w[j], 3, 2, tin, tmp, 1);
+                                tin = tmp;
+                            }
+                            srcs[i - 1 - j] = tin;
+                            ml.mconv.push_back(lp + "." + std::to_string(i - j - 1) + ".0");
+                            ml.mbn.push_back(lp + "." + std::to_string(i - j - 1) + ".1");
+                            ml.mcin.push_back(w[j]);
+                            ml.cin += w[j];
+                        }
+                        ml.conv = ml.mconv[0]; ml.bn = ml.mbn[0];
+                        n.layers.push_back(ml);
+                        Op &o = conv((int)n.layers.size() - 1, srcs[0], OUT, 1, cur);
+                        o.in2 = srcs[1]; o.in3 = srcs[2];
+                        cur = OUT;
+                        continue;
+                    }
                     for (int j = 0; j < i; ++j) {  // high -> low: chain of stride-2 convs, summed in the last epilogue
                         const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
                         int tin = x[j];
@@ -534,6 +564,34 @@ int hh_net::finalize()
         l.cin_pad = round_up(l.cin, l.KC);
         const int COUT_T = 32 * l.NT;
         l.ncg = coutp / COUT_T;
+        if (!l.mconv.empty()) {
+            // the sum of several conv + BN pairs as one conv over the concatenated input channels: every BN scale goes into its
+            // conv's weights, the shifts add up
+            std::vector<float> Wm((size_t)l.cout * l.cin * 9, 0.f), one(coutp, 1.f), shift(coutp, 0.f);
+            int c0 = 0;
+            for (size_t m = 0; m < l.mconv.size(); ++m) {
+                if (l.mcin[m] % l.KC) { hh_set_error("merged fusion conv: input width not a multiple of the chunk size"); return 1; }
+                const std::vector<float> &Wj = get(l.mconv[m] + ".weight");
+                for (int co = 0; co < l.cout; ++co) {
+                    const float g = get(l.mbn[m] + ".weight")[co], bta = get(l.mbn[m] + ".bias")[co];
+                    const float mu = get(l.mbn[m] + ".running_mean")[co], var = get(l.mbn[m] + ".running_var")[co];
+                    const float sc = g / std::sqrt(var + 1e-5f);
+                    shift[co] += bta - mu * sc;
+                    for (int ci = 0; ci < l.mcin[m]; ++ci)
+                        for (int t = 0; t < 9; ++t) Wm[((size_t)co * l.cin + c0 + ci) * 9 + t] = Wj[((size_t)co * l.mcin[m] + ci) * 9 + t] * sc;
+                }
+                c0 += l.mcin[m];
+            }
+            std::vector<bf16_raw> packed;
+            hh_pack_weights(Wm.data(), one.data(), 3, l.cin, l.cout, l.KC, COUT_T, false, 0, 0, packed);
+            if (l.d_w) { hipFree(l.d_w); l.d_w = nullptr; }
+            if (l.d_bias) { hipFree(l.d_bias); l.d_bias = nullptr; }
+            HH_CHECK_HIP(hipMalloc((void **)&l.d_w, packed.size() * 2));
+            HH_CHECK_HIP(hipMalloc((void **)&l.d_bias, (size_t)coutp * 4));
+            HH_CHECK_HIP(hipMemcpy(l.d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+            HH_CHECK_HIP(hipMemcpy(l.d_bias, shift.data(), (size_t)coutp * 4, hipMemcpyHostToDevice));
+            continue;
+        }
         const std::vector<float> &W = get(l.conv + ".weight");
         std::vector<float> scale(coutp, 0.f), shift(coutp, 0.f);
         for (int co = 0; co < l.cout; ++co) {
@@ -944,6 +1002,17 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 p.res = tr.ptr; p.res_cs = tr.C; p.res_coff = op.res_coff;
             }
             p.out_f32 = op.f32_out == 1 ? o1 : op.f32_out == 2 ? o2 : nullptr;
+            if (op.in2 >= 0) {  // conv over the concatenated channels of two or three tensors of one shape and pixel stride
+                const TensorDesc &t2 = tensors[op.in2];
+                if (t2.C != ti.C || t2.shift != ti.shift || (op.in3 >= 0 && (tensors[op.in3].C != ti.C || tensors[op.in3].shift != ti.shift))) {
+                    hh_set_error("merged fusion conv: inputs differ in shape or pixel stride");
+                    return 1;
+                }
+                p.nch0 = l.mcin[0] / l.KC;
+                p.nch1 = l.mcin[1] / l.KC;
+                p.src_delta1 = t2.ptr - (ti.ptr + op.in_coff);
+                if (op.in3 >= 0) p.src_delta2 = tensors[op.in3].ptr - (ti.ptr + op.in_coff);
+            }
             p.cin = l.cin_pad;
             p.cout_real = l.cout;
             p.cout_store = op.cout_store >= 0 ? op.cout_store : round_up(l.cout, 8);
@@ -1056,7 +1125,7 @@ int hh_net::check_plan(std::string *why) const
         if (l >= lanes_open) { if (why) *why = "op " + std::to_string(i) + " runs on a lane that was never forked"; return 1; }
         std::vector<int> rd, wr;
         switch (op.kind) {
-        case OP_CONV: rd = {op.in, op.res}; wr = {op.out}; break;
+        case OP_CONV: rd = {op.in, op.res, op.in2, op.in3}; wr = {op.out}; break;
         case OP_UPADD: rd = {op.in, op.up[0], op.up[1], op.up[2]}; wr = {op.out}; break;
         case OP_BB: rd = {op.in}; wr = {op.out}; break;
         case OP_JUNC: rd = {op.in, op.in2, op.res}; wr = {op.out, op.out2}; break;

@@ -32,6 +32,10 @@ struct ConvLayer {
     std::string conv, bn, bias;  // state-dict prefixes ("" = absent)
     int cin = 0, cout = 0, ks = 1, stride = 1;
     bool transposed = false;
+    // conv over the concatenated channels of several inputs = the SUM of several convs + BNs (the stride-2 convs a fusion layer
+    // adds up): their state-dict prefixes and input widths; `conv` / `bn` / `cin` then describe the first one / the total
+    std::vector<std::string> mconv, mbn;
+    std::vector<int> mcin;
     bool stem2 = false; // second stem conv inside stem_fused.hip: packed [tap][cin/8][64 couts][8]
     bool stem = false;  // first conv of the net: packed for stem_conv.hip (K = 27 taps padded to 32)
     bool bb128 = false; // conv of a fused 128-channel BasicBlock: packed with 16-channel chunks over all 128 couts
@@ -61,6 +65,7 @@ struct Op {
     int layer = -1, layer2 = -1;  // layer2: second conv of a fused BasicBlock / downsample conv of a junction (-1: none)
     int layer3 = -1;              // OP_JUNC: first conv of the next Bottleneck (-1: none)
     int in2 = -1, out2 = -1;      // OP_JUNC: downsample input x, and the t1 output
+    int in3 = -1;                 // OP_CONV over concatenated inputs: in, in2, in3 (ConvLayer::mcin channels each)
     int in = -1, in_coff = 0;
     int out = -1, out_coff = 0;
     int res = -1, res_coff = 0;

@@ -49,6 +49,11 @@ struct ConvParams {
     unsigned long long *stamps;  // diagnostic build (-DHH_STAMP) only
     unsigned long long *clk;     // optional {min start, max end} of the launch in wall_clock64() ticks (profiling probe)
     const bf16_raw *zero;        // >= 16 zero bytes (16-B aligned): DMA source of out-of-image pixels (conv3x3_dma.hip)
+    // Several input tensors as ONE conv over their concatenated channels (the summed stride-2 convs of a fusion layer,
+    // hrnet.py:166-229): same spatial dims and the same pixel stride as `in`; chunks [0, nch0) come from `in`, the next nch1 from
+    // in + src_delta1 elements, the rest from in + src_delta2.  nch0 = 0: a single input.
+    int nch0, nch1;
+    ptrdiff_t src_delta1, src_delta2;
 };
 
 // Tile configuration of one kernel instantiation.
