@@ -58,6 +58,22 @@ struct Builder {
         n.ops.push_back(o);
     }
 
+    // mark / waitl: a join taken apart.  mark(n) notes where every lane stands; waitl(lane, src) makes `lane` wait for lane
+    // `src`'s position at the last mark only -- a fusion output starts on the branches that are already done instead of waiting
+    // for the slowest one.
+    void mark(int nlanes)
+    {
+        Op o;
+        o.kind = OP_MARK; o.nlanes = nlanes;
+        n.ops.push_back(o);
+    }
+    void waitl(int lane_, int src)
+    {
+        Op o;
+        o.kind = OP_WAITL; o.lane = lane_; o.dep_from = src;
+        n.ops.push_back(o);
+    }
+
     void dep(int from, int to)
     {
         Op o;
@@ -317,7 +333,11 @@ struct Builder {
                     basic_blocks(hp + ".scales_blocks." + std::to_string(i), w[i], x[i], m[i], nsc, i);
                 }
                 lane = 0;
-                join(nsc);  // every fusion output reads every branch
+                // every fusion output reads every branch -- but not all of them at once: the lanes note their positions and
+                // every output waits, source by source, right in front of the first launch that needs the source
+                // (HH_FULL_JOIN=1: an all-to-all join here instead)
+                const bool fine = !getenv("HH_FULL_JOIN");
+                if (fine) mark(nsc); else join(nsc);
                 for (int i = 0; i < nsc; ++i)
                     tap("stages." + std::to_string(s) + ".blocks." + std::to_string(2 * b) + "#" + std::to_string(i), x[i], w[i]);
                 // FusionLayer (hrnet.py:166-229)
@@ -328,15 +348,22 @@ struct Builder {
                     lane = i;  // output i only writes its own tensors; it feeds branch i of the next block directly
                     const int OUT = last ? CAT : f[i];
                     int cur = x[i];
+                    bool waited[4] = {false, false, false, false};
+                    waited[i] = true;
+                    auto need = [&](int j) { if (fine && !waited[j]) { waitl(i, j); waited[j] = true; } };
+                    // OUT is the x[i] of the previous HR block, which the other lanes' fusion launches read then: before the first
+                    // write to it this lane must be behind every other lane's mark (which is behind those reads)
+                    auto need_all = [&]() { for (int j = 0; j < nsc; ++j) need(j); };
                     Op up;
                     up.kind = OP_UPADD; up.in = x[i]; up.out = OUT; up.C = w[i]; up.relu = (i == 0); up.lane = lane;
                     for (int j = i + 1; j < nsc; ++j) {  // low -> high: 1x1 conv + BN at low res
                         const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
                         const int u = T(w[i], 2 + j);
+                        need(j);
                         cb(lp, "0", "1", w[j], w[i], 1, 1, x[j], u, 0);
                         up.up[up.nup] = u; up.up_shift[up.nup] = j - i; ++up.nup;
                     }
-                    if (up.nup) { n.ops.push_back(up); cur = OUT; }
+                    if (up.nup) { need_all(); n.ops.push_back(up); cur = OUT; }
                     // high -> low, two or more sources (bf16): the LAST stride-2 conv of every chain reads at the resolution above the
                     // output's, so the sum of those convs is one conv over the concatenated channels -- one launch instead of i
                     // dependent ones on the lane that already has the longest chain.  Its inputs must share a pixel stride: chain
@@ -348,6 +375,7 @@ struct Builder {
                         for (int j = i - 1; j >= 0; --j) {  // source order: branch i-1 itself first, then the chains
                             const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
                             int tin = x[j];
+                            need(j);
                             for (int k = 0; k < i - j - 1; ++k) {
                                 const bool last_tmp = k == i - j - 2;
                                 const int tmp = T(last_tmp ? w[i - 1] : w[j], 2 + j + k + 1);  // (stride of branch i-1 for the merged conv's inputs)
@@ -362,6 +390,7 @@ struct Builder {
                         }
                         ml.conv = ml.mconv[0]; ml.bn = ml.mbn[0];
                         n.layers.push_back(ml);
+                        need_all();
                         Op &o = conv((int)n.layers.size() - 1, srcs[0], OUT, 1, cur);
                         o.in2 = srcs[1]; o.in3 = srcs[2];
                         cur = OUT;
@@ -370,11 +399,13 @@ struct Builder {
                     for (int j = 0; j < i; ++j) {  // high -> low: chain of stride-2 convs, summed in the last epilogue
                         const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
                         int tin = x[j];
+                        need(j);
                         for (int k = 0; k < i - j - 1; ++k) {
                             const int tmp = T(w[j], 2 + j + k + 1);
                             cb(lp + "." + std::to_string(k), "0", "1", w[j], w[j], 3, 2, tin, tmp, 1);
                             tin = tmp;
                         }
+                        need_all();
                         cb(lp + "." + std::to_string(i - j - 1), "0", "1", w[j], w[i], 3, 2, tin, OUT, j == i - 1, cur);
                         cur = OUT;
                     }
@@ -757,6 +788,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         HH_CHECK_HIP(hipMemcpy(d_clk, init.data(), init.size() * 8, hipMemcpyHostToDevice));
     }
     int lanes_open = 1;  // lanes [0, lanes_open) have work that the caller's stream must wait for at the end
+    hipEvent_t mark_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     for (const Op &op : ops) {
         hipStream_t s = L[op.lane];
         switch (op.kind) {
@@ -774,6 +806,21 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 for (int m = 0; m < nrec; ++m)
                     if (m != l) HH_CHECK_HIP(hipStreamWaitEvent(L[l], e[m], 0));
             if (op.nlanes > lanes_open) lanes_open = op.nlanes;
+            break;
+        }
+        case OP_MARK: {
+            if (!multi) break;
+            const int nrec = op.nlanes < lanes_open ? op.nlanes : lanes_open;
+            for (int l = 0; l < nrec; ++l) {
+                if (next_event(&mark_ev[l])) return 1;
+                HH_CHECK_HIP(hipEventRecord(mark_ev[l], L[l]));
+            }
+            if (op.nlanes > lanes_open) lanes_open = op.nlanes;
+            break;
+        }
+        case OP_WAITL: {
+            if (!multi) break;
+            HH_CHECK_HIP(hipStreamWaitEvent(L[op.lane], mark_ev[op.dep_from], 0));
             break;
         }
         case OP_DEP: {
@@ -1101,6 +1148,7 @@ int hh_net::check_plan(std::string *why) const
 {
     struct Stamp { int lane; int t; int op; };
     int clk[4][4] = {};  // clk[l][m] = latest event of lane m that lane l is ordered after
+    int mark_clk[4][4] = {};  // the lanes' clocks at the last OP_MARK
     auto before = [&](const Stamp &st, int lane) { return st.lane < 0 || clk[lane][st.lane] >= st.t; };
     std::vector<Stamp> writer(tensors.size(), Stamp{-1, 0, -1});
     std::vector<std::vector<Stamp>> readers(tensors.size());
@@ -1119,6 +1167,17 @@ int hh_net::check_plan(std::string *why) const
         }
         if (op.kind == OP_DEP) {
             for (int c = 0; c < 4; ++c) clk[op.lane][c] = std::max(clk[op.lane][c], clk[op.dep_from][c]);
+            continue;
+        }
+        if (op.kind == OP_MARK) {
+            const int nrec = op.nlanes < lanes_open ? op.nlanes : lanes_open;
+            for (int m = 0; m < nrec; ++m)
+                for (int c = 0; c < 4; ++c) mark_clk[m][c] = clk[m][c];
+            if (op.nlanes > lanes_open) lanes_open = op.nlanes;
+            continue;
+        }
+        if (op.kind == OP_WAITL) {
+            for (int c = 0; c < 4; ++c) clk[op.lane][c] = std::max(clk[op.lane][c], mark_clk[op.dep_from][c]);
             continue;
         }
         const int l = op.lane;

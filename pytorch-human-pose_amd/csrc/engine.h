@@ -58,7 +58,7 @@ struct TensorDesc {
     bool shared_scale = false;  // fp8: written in channel slices by several ops (torch.cat buffer): one scale for all of them
 };
 
-enum OpKind { OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC, OP_STEM };
+enum OpKind { OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC, OP_STEM, OP_MARK, OP_WAITL };
 
 struct Op {
     OpKind kind = OP_CONV;
@@ -78,7 +78,8 @@ struct Op {
     int tap = -1;
     int lane = 0;     // execution lane (HIP stream): resolution branches / fusion outputs run concurrently
     int nlanes = 0;   // OP_JOIN: all-to-all barrier over lanes [0, nlanes)
-    int dep_from = 0; // OP_DEP: `lane` waits for everything enqueued so far on lane dep_from
+    int dep_from = 0; // OP_DEP: `lane` waits for everything enqueued so far on lane dep_from; OP_WAITL: `lane` waits for lane dep_from's
+                      // position at the last OP_MARK (OP_MARK: every lane [0, nlanes) records its position)
     // fp8 path: tensor scales seen by this op (real value = e4m3 * scale), resolved from the calibration maxima
     float s_in = 1.f, s_in2 = 1.f, s_res = 1.f, s_out = 1.f, s_up[3] = {1.f, 1.f, 1.f};
     float s_mid = 1.f;  // fused fp8 BasicBlock: scale of the intermediate tile

@@ -204,6 +204,18 @@ def test_multi_lane_schedule_has_no_unordered_hazard(pkg):
     lib = pkg._lib.load()
     for net in (pkg.HigherHRNet(17, 32), pkg.HigherHRNet(17, 48), pkg.HigherHRNet(5, 32), pkg.ClassificationHRNet(32, 10)):
         assert lib.hh_debug_check_plan(net._h) == 0, lib.hh_last_error().decode()
+    # the plan variants behind the experiment switches (read when the plan is built) and the fp8 plan
+    import os
+    for env in ({"HH_NO_FUSION_MERGE": "1"}, {"HH_FULL_JOIN": "1"}, {"HH_FULL_JOIN": "1", "HH_NO_FUSION_MERGE": "1"}, {"HH_NO_STEM_FUSED": "1"}):
+        os.environ.update(env)
+        try:
+            nets = (pkg.HigherHRNet(17, 32), pkg.HigherHRNet(17, 48))
+        finally:
+            for k in env:
+                del os.environ[k]
+        for net in nets:
+            assert lib.hh_debug_check_plan(net._h) == 0, (env, lib.hh_last_error().decode())
+    assert lib.hh_debug_check_plan(pkg.HigherHRNet(17, 48, dtype="fp8")._h) == 0, lib.hh_last_error().decode()
 
 
 def test_keypoints_model_init_weights_and_wrappers():
