@@ -420,7 +420,9 @@ struct Builder {
             if (s < 3) {  // TransitionLayer: only the new lowest branch has parameters (hrnet.py:262-283)
                 const std::string q = sp + ".transition_layer.transition_blocks." + std::to_string(nsc);
                 x[nsc] = T(w[nsc], 2 + nsc);
-                join(nsc + 1);
+                // the new lane needs branch nsc-1's fusion output only, the others go straight on to the next stage's blocks
+                if (!getenv("HH_FULL_JOIN")) { mark(nsc + 1); waitl(nsc, nsc - 1); }
+                else join(nsc + 1);
                 lane = nsc;  // the new branch starts on its own lane
                 cb(q, "0", "1", w[nsc - 1], w[nsc], 3, 2, x[nsc - 1], x[nsc], 1);
                 // write-after-read: branch nsc-1 of the next stage updates x[nsc-1] in place (conv2 of its first
@@ -429,7 +431,9 @@ struct Builder {
                 lane = 0;
                 for (int i = 0; i <= nsc; ++i) tap("stages." + std::to_string(s) + "#" + std::to_string(i), x[i], w[i]);
             } else {
-                join(4);
+                // HigherHRNet: only lane 0 goes on (it has waited for the others source by source); the forward's closing edges
+                // collect the rest.  The classification head reads all four branches on lane 0.
+                if (n.kind != 0 || getenv("HH_FULL_JOIN")) join(4);
                 if (n.kind == 0) tap("stages.3#0", CAT, w[0]);
             }
         }
