@@ -372,17 +372,22 @@ struct Builder {
                         int srcs[3] = {-1, -1, -1};
                         ConvLayer ml;
                         ml.cout = w[i]; ml.ks = 3; ml.stride = 2; ml.cin = 0;
-                        for (int j = i - 1; j >= 0; --j) {  // source order: branch i-1 itself first, then the chains
+                        int tins[3] = {-1, -1, -1};
+                        for (int j = 0; j < i; ++j) {  // the chains, highest resolution first: those branches are done first
                             const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
                             int tin = x[j];
-                            need(j);
+                            if (j < i - 1) need(j);  // (branch i-1 feeds the merged conv directly: waited for in need_all below)
                             for (int k = 0; k < i - j - 1; ++k) {
                                 const bool last_tmp = k == i - j - 2;
                                 const int tmp = T(last_tmp ? w[i - 1] : w[j], 2 + j + k + 1);  // (stride of branch i-1 for the merged conv's inputs)
                                 cb(lp + "." + std::to_string(k), "0", "1", w[j], w[j], 3, 2, tin, tmp, 1);
                                 tin = tmp;
                             }
-                            srcs[i - 1 - j] = tin;
+                            tins[j] = tin;
+                        }
+                        for (int j = i - 1; j >= 0; --j) {  // source order of the merged conv: branch i-1 itself first, then the chains
+                            const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
+                            srcs[i - 1 - j] = tins[j];
                             ml.mconv.push_back(lp + "." + std::to_string(i - j - 1) + ".0");
                             ml.mbn.push_back(lp + "." + std::to_string(i - j - 1) + ".1");
                             ml.mcin.push_back(w[j]);
