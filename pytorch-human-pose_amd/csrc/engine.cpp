@@ -262,6 +262,16 @@ struct Builder {
         // bf16: both stem convolutions in ONE kernel (stem_fused.hip), the half-resolution intermediate never leaves the CU
         // (HH_NO_STEM_FUSED=1 and the fp8 path: two launches through the tensor S1)
         const bool stem_fused = n.dtype != 2 && !getenv("HH_NO_STEM_FUSED");
+        // Stem and stage 0 are one chain of launches on one resolution.  HH_STAGE0_PARTS=2|4 runs them as part batches on as many
+        // lanes (images are independent), one part's HBM-bound junction kernel beside another's 3x3 conv.  OFF by default: in the
+        // trace the phase shrinks from 1035 to 894 us, but the junctions of the parts mostly run in step (they are 70 % of a
+        // chain) and over the whole forward nothing is left of it (4.63 / 4.68 ms with, 4.62 / 4.67 without; four parts the same).
+        n.split_parts = getenv("HH_STAGE0_PARTS") ? atoi(getenv("HH_STAGE0_PARTS")) : 1;
+        if (n.split_parts != 4 && n.split_parts != 2) n.split_parts = 1;
+        if (n.dtype == 2) n.split_parts = 1;
+        const bool split0 = n.split_parts > 1;
+        if (split0) join(n.split_parts);
+        const size_t split_first = n.ops.size();
         const int S1 = stem_fused ? -1 : T(64, 1), X = T(64, 2);
         {   // conv1 reads the fp32 NCHW images itself (stem_conv.hip): no layout pass, no padded input channels
             Op o;
@@ -274,7 +284,6 @@ struct Builder {
             n.ops.push_back(o);
         }
         if (!stem_fused) conv(L(bb + ".conv2", bb + ".bn2", 64, 64, 3, 2), S1, X, 1);
-        tap("stem#0", X, 64);
 
         // stage 0: four Bottlenecks on one scale (hrnet.py:29-74), then the 256->C / 256->2C transition
         const int t1 = T(64, 2), t2 = T(64, 2), Y = T(256, 2);
@@ -301,6 +310,17 @@ struct Builder {
             o.out = Y; o.out2 = u < 3 ? t1 : -1;
             n.ops.push_back(o);
         }
+        if (split0) {  // the chain above becomes half 0 on lane 0, a copy of it half 1 on lane 1
+            const size_t split_last = n.ops.size();
+            for (size_t i = split_first; i < split_last; ++i) { n.ops[i].half = 0; n.ops[i].lane = 0; }
+            for (int part = 1; part < n.split_parts; ++part)
+                for (size_t i = split_first; i < split_last; ++i) {
+                    Op o = n.ops[i];
+                    o.half = part; o.lane = part;
+                    n.ops.push_back(o);
+                }
+        }
+        tap("stem#0", X, 64);
         tap("stages.0.blocks.0#0", Y, 256);
         tap("stages.0.blocks.1#0", Y, 256);  // single-scale fusion = ReLU of a ReLU output
         int x[4] = {-1, -1, -1, -1}, m[4], f[4];
@@ -308,7 +328,7 @@ struct Builder {
         x[0] = T(w[0], 2); x[1] = T(w[1], 3);
         {
             const std::string tp = bb + ".stages.0.transition_layer.transition_blocks";
-            join(2);
+            join(n.split_parts > 2 ? n.split_parts : 2);
             lane = 0; cb(tp + ".0", "0", "1", 256, w[0], 3, 1, Y, x[0], 1);
             lane = 1; cb(tp + ".1", "0", "1", 256, w[1], 3, 2, Y, x[1], 1);
             lane = 0;
@@ -798,8 +818,20 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
     }
     int lanes_open = 1;  // lanes [0, lanes_open) have work that the caller's stream must wait for at the end
     hipEvent_t mark_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    const int Bfull = B;
     for (const Op &op : ops) {
         hipStream_t s = L[op.lane];
+        // half-batch ops: B / boff replace the batch size and select the images (every tensor is batch-major)
+        int boff = 0;
+        B = Bfull;
+        if (op.half >= 0 && Bfull < 4 * split_parts) {  // small batches: the extra launches cost more than the overlap gives; part 0 takes all
+            if (op.half > 0) continue;
+        } else if (op.half >= 0) {
+            const int B0 = (Bfull + split_parts - 1) / split_parts;
+            boff = op.half * B0;
+            B = Bfull - boff < B0 ? Bfull - boff : B0;
+            if (B <= 0) continue;
+        }
         switch (op.kind) {
         case OP_JOIN: {
             if (!multi) break;
@@ -845,8 +877,8 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             if (op.layer2 >= 0) {  // both stem convolutions in one kernel
                 const ConvLayer &l2 = layers[op.layer2];
                 StemFusedParams q{};
-                q.images = images; q.w1 = l.d_w; q.b1 = l.d_bias; q.w2 = l2.d_w; q.b2 = l2.d_bias;
-                q.out = tensors[op.out].ptr; q.out_cs = tensors[op.out].C;
+                q.images = images + (size_t)boff * 3 * H * W; q.w1 = l.d_w; q.b1 = l.d_bias; q.w2 = l2.d_w; q.b2 = l2.d_bias;
+                q.out = tensors[op.out].ptr + (size_t)boff * (H / 4) * (W / 4) * tensors[op.out].C; q.out_cs = tensors[op.out].C;
                 q.B = B; q.H = H; q.W = W;
                 if (!stem_fused_supported(q)) { hh_set_error("hh_forward: the fused stem needs H, W multiples of 4 and images below 2 GB (HH_NO_STEM_FUSED=1)"); return 1; }
                 if (prof_enabled) {
@@ -869,8 +901,8 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 break;
             }
             StemParams p{};
-            p.images = images; p.w = l.d_w; p.bias = l.d_bias;
-            p.out = tensors[op.out].ptr; p.out_cs = tensors[op.out].C;
+            p.images = images + (size_t)boff * 3 * H * W; p.w = l.d_w; p.bias = l.d_bias;
+            p.out = tensors[op.out].ptr + (size_t)boff * (H / 2) * (W / 2) * tensors[op.out].C; p.out_cs = tensors[op.out].C;
             p.B = B; p.H = H; p.W = W;
             if (dtype == 2) {
                 p.out_fp8 = (unsigned char *)tensors[op.out].ptr; p.out_inv_scale = 1.f / op.s_out;
@@ -937,13 +969,14 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         case OP_JUNC: {
             const ConvLayer &l3 = layers[op.layer];
             JuncParams p{};
-            p.t2 = tensors[op.in].ptr; p.t2_cs = tensors[op.in].C;
-            if (op.res >= 0) { p.res = tensors[op.res].ptr; p.res_cs = tensors[op.res].C; }
-            if (op.in2 >= 0) { p.x = tensors[op.in2].ptr; p.x_cs = tensors[op.in2].C; p.wd = layers[op.layer2].d_w; p.bd = layers[op.layer2].d_bias; }
-            p.w3 = l3.d_w; p.b3 = l3.d_bias;
-            if (op.layer3 >= 0) { p.w1 = layers[op.layer3].d_w; p.b1 = layers[op.layer3].d_bias; p.t1 = tensors[op.out2].ptr; p.t1_cs = tensors[op.out2].C; }
-            p.y = tensors[op.out].ptr; p.y_cs = tensors[op.out].C;
             const TensorDesc &ti = tensors[op.in];
+            const size_t pix0 = (size_t)boff * (H >> ti.shift) * (W >> ti.shift);  // first pixel of this op's images
+            p.t2 = tensors[op.in].ptr + pix0 * tensors[op.in].C; p.t2_cs = tensors[op.in].C;
+            if (op.res >= 0) { p.res = tensors[op.res].ptr + pix0 * tensors[op.res].C; p.res_cs = tensors[op.res].C; }
+            if (op.in2 >= 0) { p.x = tensors[op.in2].ptr + pix0 * tensors[op.in2].C; p.x_cs = tensors[op.in2].C; p.wd = layers[op.layer2].d_w; p.bd = layers[op.layer2].d_bias; }
+            p.w3 = l3.d_w; p.b3 = l3.d_bias;
+            if (op.layer3 >= 0) { p.w1 = layers[op.layer3].d_w; p.b1 = layers[op.layer3].d_bias; p.t1 = tensors[op.out2].ptr + pix0 * tensors[op.out2].C; p.t1_cs = tensors[op.out2].C; }
+            p.y = tensors[op.out].ptr + pix0 * tensors[op.out].C; p.y_cs = tensors[op.out].C;
             p.npix = B * (H >> ti.shift) * (W >> ti.shift);
             ProfRecord *pr = nullptr;
             if (prof_enabled) {
@@ -1036,8 +1069,8 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             const ConvLayer &l = layers[op.layer];
             const TensorDesc &ti = tensors[op.in];
             ConvParams p{};
-            p.in = ti.ptr; p.in_cs = ti.C; p.in_coff = op.in_coff;
             p.Hin = H >> ti.shift; p.Win = W >> ti.shift;
+            p.in = ti.ptr + (size_t)boff * p.Hin * p.Win * ti.C; p.in_cs = ti.C; p.in_coff = op.in_coff;
             p.w = l.d_w; p.bias = l.d_bias;
             p.Ho = l.stride == 2 ? p.Hin / 2 : p.Hin;
             p.Wo = l.stride == 2 ? p.Win / 2 : p.Win;
@@ -1051,11 +1084,11 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             p.Hob = p.Ho * p.osy; p.Wob = p.Wo * p.osx;
             if (op.out >= 0) {
                 const TensorDesc &to = tensors[op.out];
-                p.out = to.ptr; p.out_cs = to.C; p.out_coff = op.out_coff;
+                p.out = to.ptr + (size_t)boff * p.Hob * p.Wob * to.C; p.out_cs = to.C; p.out_coff = op.out_coff;
             }
             if (op.res >= 0) {
                 const TensorDesc &tr = tensors[op.res];
-                p.res = tr.ptr; p.res_cs = tr.C; p.res_coff = op.res_coff;
+                p.res = tr.ptr + (size_t)boff * p.Hob * p.Wob * tr.C; p.res_cs = tr.C; p.res_coff = op.res_coff;
             }
             p.out_f32 = op.f32_out == 1 ? o1 : op.f32_out == 2 ? o2 : nullptr;
             if (op.in2 >= 0) {  // conv over the concatenated channels of two or three tensors of one shape and pixel stride
@@ -1105,6 +1138,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         }
         }
     }
+    B = Bfull;
     if (multi)
         for (int l = 1; l < lanes_open; ++l) {  // close the fork: the caller's stream waits for every lane
             hipEvent_t e;
@@ -1159,8 +1193,9 @@ int hh_net::check_plan(std::string *why) const
     int clk[4][4] = {};  // clk[l][m] = latest event of lane m that lane l is ordered after
     int mark_clk[4][4] = {};  // the lanes' clocks at the last OP_MARK
     auto before = [&](const Stamp &st, int lane) { return st.lane < 0 || clk[lane][st.lane] >= st.t; };
-    std::vector<Stamp> writer(tensors.size(), Stamp{-1, 0, -1});
-    std::vector<std::vector<Stamp>> readers(tensors.size());
+    // (every tensor counts as four resources, quarters of the batch: an op on part `half` of the batch touches that part's)
+    std::vector<Stamp> writer(4 * tensors.size(), Stamp{-1, 0, -1});
+    std::vector<std::vector<Stamp>> readers(4 * tensors.size());
     int lanes_open = 1;
     for (size_t i = 0; i < ops.size(); ++i) {
         const Op &op = ops[i];
@@ -1202,11 +1237,21 @@ int hh_net::check_plan(std::string *why) const
         case OP_AVGPOOL: rd = {op.in}; break;
         default: break;
         }
+        {   // tensor ids -> (tensor, half) resources
+            std::vector<int> rd2, wr2;
+            const int per = 4 / (split_parts > 1 ? split_parts : 1);  // sub-resources of one part
+            for (int q = 0; q < 4; ++q) {
+                if (op.half >= 0 && q / per != op.half) continue;
+                for (int x : rd) if (x >= 0) rd2.push_back(4 * x + q);
+                for (int x : wr) if (x >= 0) wr2.push_back(4 * x + q);
+            }
+            rd.swap(rd2); wr.swap(wr2);
+        }
         const int t = ++clk[l][l];
         for (int x : rd) {
             if (x < 0) continue;
             if (!before(writer[x], l)) {
-                if (why) *why = "RAW: op " + std::to_string(i) + " (lane " + std::to_string(l) + ") reads tensor " + std::to_string(x) +
+                if (why) *why = "RAW: op " + std::to_string(i) + " (lane " + std::to_string(l) + ") reads tensor " + std::to_string(x >> 2) +
                                 " written by op " + std::to_string(writer[x].op) + " (lane " + std::to_string(writer[x].lane) + ") without an edge";
                 return 1;
             }
@@ -1214,12 +1259,12 @@ int hh_net::check_plan(std::string *why) const
         for (int x : wr) {
             if (x < 0) continue;
             if (!before(writer[x], l)) {
-                if (why) *why = "WAW: op " + std::to_string(i) + " overwrites tensor " + std::to_string(x) + " of op " + std::to_string(writer[x].op);
+                if (why) *why = "WAW: op " + std::to_string(i) + " overwrites tensor " + std::to_string(x >> 2) + " of op " + std::to_string(writer[x].op);
                 return 1;
             }
             for (const Stamp &r : readers[x])
                 if (!(r.lane == l) && !before(r, l)) {
-                    if (why) *why = "WAR: op " + std::to_string(i) + " (lane " + std::to_string(l) + ") overwrites tensor " + std::to_string(x) +
+                    if (why) *why = "WAR: op " + std::to_string(i) + " (lane " + std::to_string(l) + ") overwrites tensor " + std::to_string(x >> 2) +
                                     " still read by op " + std::to_string(r.op) + " (lane " + std::to_string(r.lane) + ")";
                     return 1;
                 }

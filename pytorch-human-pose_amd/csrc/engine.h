@@ -76,6 +76,8 @@ struct Op {
     int up[3] = {-1, -1, -1}, up_shift[3] = {0, 0, 0}, nup = 0;
     int C = 0;  // UPADD channel count / TAP channel count
     int tap = -1;
+    int half = -1;    // >= 0: the op works on part `half` of the batch only (hh_net::split_parts equal parts: stem + stage 0 run as
+                      // part batches on as many lanes: one part's HBM-bound junction beside another's 3x3 conv); -1: the whole batch
     int lane = 0;     // execution lane (HIP stream): resolution branches / fusion outputs run concurrently
     int nlanes = 0;   // OP_JOIN: all-to-all barrier over lanes [0, nlanes)
     int dep_from = 0; // OP_DEP: `lane` waits for everything enqueued so far on lane dep_from; OP_WAITL: `lane` waits for lane dep_from's
@@ -141,6 +143,7 @@ struct hh_net {
     std::vector<hipEvent_t> lane_events;
     size_t lane_events_used = 0;
     bool multi_lane = true;
+    int split_parts = 1;     // number of part batches stem + stage 0 run as (HH_STAGE0_PARTS = 2 or 4; default 1 = not split)
     bool bb32_pc = true;     // the producer / consumer form of the fused 32-channel block (HH_BB32=tile selects the tile form)
     bool bb32_thin = false;  // HH_BB32=thin: the half-CU variant of the fused 32-channel block (experiment switch)
     // fp8 path (dtype == HH_DTYPE_FP8)

@@ -153,6 +153,23 @@ def test_fused_stem_matches_two_launches(pkg, net_golden):
             assert (u - v).abs().max().item() <= 4e-2 * v.abs().max().item() and (u - v).pow(2).mean().sqrt().item() <= 2e-2 * v.pow(2).mean().sqrt().item(), shape
 
 
+def test_stage0_part_batches_opt_in(pkg):
+    """HH_STAGE0_PARTS=2|4 (off by default): stem + stage 0 as part batches on separate lanes.  Images are
+    independent and every part runs the same kernels, so the outputs equal the unsplit plan's bit for bit -- odd batch included."""
+    x = torch.from_numpy(pkg.synth.synth_images(9, 64, 96, 3)).to(DEV)
+    ref_net, _ = _net(pkg, 32, 2)
+    ref = [t.clone() for t in ref_net.forward_raw(x)]
+    for parts in ("2", "4"):
+        os.environ["HH_STAGE0_PARTS"] = parts
+        try:
+            net, _ = _net(pkg, 32, 2)
+        finally:
+            del os.environ["HH_STAGE0_PARTS"]
+        for _ in range(3):
+            got = net.forward_raw(x)
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), parts
+
+
 def test_forward_full_size_samples_and_batch_consistency(pkg, net_golden):
     net, _ = _net(pkg, 32, 0)
     x1 = torch.from_numpy(pkg.synth.synth_images(1, 512, 512, 7)).to(DEV)
