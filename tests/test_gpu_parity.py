@@ -170,6 +170,30 @@ def test_stage0_part_batches_opt_in(pkg):
             assert all(torch.equal(a, b) for a, b in zip(got, ref)), parts
 
 
+def test_schedule_and_fusion_switches(pkg, net_golden):
+    """The plan variants behind the engine switches: all-to-all joins (HH_FULL_JOIN=1) give the default plan's bits (same kernels,
+    other edges); one launch per summed stride-2 conv (HH_NO_FUSION_MERGE=1) rounds the partial sums to bf16 between the launches
+    and so differs from the merged conv by bf16 noise only; both meet the golden tolerance."""
+    x = torch.from_numpy(pkg.synth.synth_images(2, 128, 128, 1)).to(DEV)
+    base, _ = _net(pkg, 32, 1)
+    ref = [t.clone() for t in base.forward_raw(x)]
+    for env, exact in ((("HH_FULL_JOIN", "1"), True), (("HH_NO_FUSION_MERGE", "1"), False)):
+        os.environ[env[0]] = env[1]
+        try:
+            net, _ = _net(pkg, 32, 1)
+        finally:
+            del os.environ[env[0]]
+        hms, tags = net(x)
+        _close(hms[0].cpu().numpy(), net_golden["w32_128/hm_q"], "hm_q")
+        _close(hms[1].cpu().numpy(), net_golden["w32_128/hm_h"], "hm_h")
+        got = net.forward_raw(x)
+        if exact:
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), env
+        else:
+            for a, b in zip(got, ref):
+                assert (a - b).abs().max().item() <= 4e-2 * b.abs().max().item() and (a - b).pow(2).mean().sqrt().item() <= 2e-2 * b.pow(2).mean().sqrt().item()
+
+
 def test_forward_full_size_samples_and_batch_consistency(pkg, net_golden):
     net, _ = _net(pkg, 32, 0)
     x1 = torch.from_numpy(pkg.synth.synth_images(1, 512, 512, 7)).to(DEV)
