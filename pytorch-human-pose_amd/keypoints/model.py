@@ -253,14 +253,18 @@ class InferenceKeypointsModel:
         """model.py:79-94 on a batch [B,3,h,w]: net forward (+ flipped pass, un-flip, joint permutation,
         heatmap average). Returns ([hm_1/4, hm_1/2], [tags] or [tags, tags_flipped])."""
         K = self.net.num_kpts
-        init, dec = self.net.forward_raw(x)
         if not self.use_flip:
+            init, dec = self.net.forward_raw(x)
             return [init[:, :K], dec], [init[:, K:]]
         B, _, H, W = x.shape
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        xf = torch.empty_like(x)
-        _lib.check(self._lib.hh_flip_images(x.data_ptr(), xf.data_ptr(), B, 3, H, W, stream))
-        init_f, dec_f = self.net.forward_raw(xf)
+        # the images and their mirror images as ONE batch of 2B: images of a batch are independent (same bits as two passes), and
+        # a forward costs ~2 ms of launch structure whatever the batch -- a single image is a chain of ~350 dependent launches
+        x2 = torch.empty((2 * B, 3, H, W), device=x.device, dtype=x.dtype)
+        x2[:B].copy_(x)
+        _lib.check(self._lib.hh_flip_images(x.data_ptr(), x2[B:].data_ptr(), B, 3, H, W, stream))
+        init2, dec2 = self.net.forward_raw(x2)
+        init, init_f, dec, dec_f = init2[:B], init2[B:], dec2[:B], dec2[B:]
         tags2 = torch.empty((B, K, H // 4, W // 4), device=x.device, dtype=torch.float32)
         hq, wq = H // 4, W // 4
         p = self._perm.ctypes.data
@@ -317,7 +321,7 @@ class InferenceKeypointsModel:
             """device -> host results of one enqueued batch, un-warp, result objects"""
             chunk, (w, h), x, hms, tags, host_out, done = job
             done.synchronize()
-            lists = self._parser.to_lists(*host_out)
+            lists = self._parser.to_lists(*host_out)  # (copies what it returns: the pinned buffers are reused two batches later)
             self.model_input_shape = (h, w)
             for j, i in enumerate(chunk):
                 joints, scores = lists[j]
@@ -355,7 +359,7 @@ class InferenceKeypointsModel:
                     copied = torch.cuda.Event()
                     copied.record()
 
-                def run(chunk=chunk, raw=raw, copied=copied, offs=offs, w=w, h=h):
+                def run(chunk=chunk, raw=raw, copied=copied, offs=offs, w=w, h=h, turn=turn):
                     torch.cuda.current_stream(self.device).wait_event(copied)
                     raw.record_stream(torch.cuda.current_stream(self.device))
                     x = torch.empty((len(chunk), 3, h, w), device=self.device, dtype=torch.float32)
@@ -368,7 +372,13 @@ class InferenceKeypointsModel:
                                                                   mean, std, stream))
                     hms, tags = self.forward_tta(x)
                     out = self._parser.decode_batch_device(hms[0], hms[1], tags, adjust=True, refine=True)
-                    host_out = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True) for t in out]
+                    # device -> host into pinned buffers kept per pipeline slot (allocating pinned memory costs ~0.4 ms per array);
+                    # finish() of this slot's previous batch ran before this point and copied what it keeps
+                    key = (turn, tuple((tuple(t.shape), t.dtype) for t in out))
+                    ring = self.__dict__.setdefault("_out_ring", {})
+                    if key not in ring:
+                        ring[key] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out]
+                    host_out = [h.copy_(t, non_blocking=True) for h, t in zip(ring[key], out)]
                     done = torch.cuda.Event()
                     done.record()
                     return (chunk, (w, h), x, hms, tags, host_out, done), copied, raw
