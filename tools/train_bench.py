@@ -12,7 +12,7 @@ net = pkg.HigherHRNet(K, 32)
 net.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()})
 net = net.cuda().train()
 loss_fn = pkg.AEKeypointsLoss()
-opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+opt = torch.optim.Adam(net.parameters(), lr=1e-4, **({"fused": True} if os.environ.get("HH_FUSED_ADAM") else {}))
 x = torch.from_numpy(pkg.synth.synth_images(B, S, S, 0)).cuda()
 hms, masks, joints = pkg.synth.synth_train_targets(B, K, S, 10, seed=0)
 hms = [torch.from_numpy(h).cuda() for h in hms]; masks = [torch.from_numpy(m).cuda() for m in masks]
