@@ -89,6 +89,10 @@ __device__ __forceinline__ void lds_wait(u32x4 &v)
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
+#ifndef BBPC_STORE_AUX
+#define BBPC_STORE_AUX 0  // cache policy bits of the output stores.  Experiment: 2 (nt) makes the block itself faster when its output is never
+                          // read (128x128: 28.5 -> 25.4 us in tools/bb_compare.py) and the forward SLOWER (4.67 -> 4.72 ms): the next launch reads it
+#endif
 constexpr int TH = 14, TW = 32;          // output tile
 constexpr int MH = TH + 2, MW = TW + 2;  // conv1 output (= conv2 input) tile: 16 x 34
 constexpr int IH = TH + 4, IW = TW + 4;  // input patch: 18 x 36
@@ -366,8 +370,8 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
 #else
                     const unsigned voff = ok ? (unsigned)(((g.b * p.H + oy) * p.W + ox) * p.out_cs * 2 + 16 * h) : OOB;
 #endif
-                    __builtin_amdgcn_raw_buffer_store_b128(o[0], rs_out, (int)voff, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(o[1], rs_out, (int)voff, 32, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o[0], rs_out, (int)voff, 0, BBPC_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(o[1], rs_out, (int)voff, 32, BBPC_STORE_AUX);
                 }
             };
             for (int it = 0; it <= nloc; ++it) {
