@@ -55,15 +55,21 @@ constexpr int W3_BYTES = 256 * 64 * 2;  // conv3 / downsample: packed [cout grou
 constexpr int W1_BYTES = 64 * 256 * 2;  // next conv1: packed [chunk 8][c8 4][64][8]
 }  // namespace
 
-// HAS_DS: unit 0 (residual = downsample conv of x, folded in as 4 more k-steps); otherwise residual = p.res (256 ch)
-template <bool HAS_DS>
-__global__ __launch_bounds__(256, 2) void junction_kernel(const JuncParams p)
+// MODE 0: residual = p.res (256 ch).   MODE 1: unit 0 -- residual = downsample conv of x, folded in as 4 more k-steps.
+// MODE 2 / 3 ("pair"): the y of the PREVIOUS unit is not read from HBM but made again, per pixel, from that unit's t2 (p.t2a,
+// weights p.w3a) -- MODE 2: the previous unit is unit 0 (+ downsample of x), MODE 3: a plain unit on top of p.res -- and used,
+// rounded to bf16 exactly as it would have been stored, as the residual of this unit.  The previous junction then does not
+// store its y at all (p.y == nullptr there): stage 0 moves a quarter less through HBM for two more 1x1 GEMMs per pair.
+template <int MODE>
+__global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void junction_kernel(const JuncParams p)
 {
+    constexpr bool HAS_DS = MODE == 1 || MODE == 2, PAIR = MODE >= 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *lds_w3 = smem;
-    char *lds_wd = smem + W3_BYTES;                          // only when HAS_DS
-    char *lds_w1 = smem + (HAS_DS ? 2 : 1) * W3_BYTES;
-    float *lds_b = reinterpret_cast<float *>(lds_w1 + W1_BYTES);  // [256] y shift, [64] t1 shift
+    char *lds_w3 = smem;                                           // this unit's conv3
+    char *lds_wd = smem + W3_BYTES;                                // only when HAS_DS
+    char *lds_w3a = smem + (HAS_DS ? 2 : 1) * W3_BYTES;            // only when PAIR: the previous unit's conv3
+    char *lds_w1 = smem + ((HAS_DS ? 2 : 1) + (PAIR ? 1 : 0)) * W3_BYTES;
+    float *lds_b = reinterpret_cast<float *>(lds_w1 + W1_BYTES);   // [256] y shift, [64] t1 shift, [256] previous y shift (PAIR)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
 #ifndef HH_NO_CLK
@@ -72,10 +78,13 @@ __global__ __launch_bounds__(256, 2) void junction_kernel(const JuncParams p)
     for (int u = tid; u < W3_BYTES / 16; u += 256) {
         reinterpret_cast<u32x4 *>(lds_w3)[u] = reinterpret_cast<const u32x4 *>(p.w3)[u];
         if (HAS_DS) reinterpret_cast<u32x4 *>(lds_wd)[u] = reinterpret_cast<const u32x4 *>(p.wd)[u];
+        if (PAIR) reinterpret_cast<u32x4 *>(lds_w3a)[u] = reinterpret_cast<const u32x4 *>(p.w3a)[u];
         if (p.w1) reinterpret_cast<u32x4 *>(lds_w1)[u] = reinterpret_cast<const u32x4 *>(p.w1)[u];
     }
-    lds_b[tid] = p.b3[tid] + (HAS_DS ? p.bd[tid] : 0.f);
+    // the downsample shift belongs to the unit the downsample conv belongs to: this one (MODE 1) or the previous one (MODE 2)
+    lds_b[tid] = p.b3[tid] + (MODE == 1 ? p.bd[tid] : 0.f);
     if (tid < 64) lds_b[256 + tid] = p.w1 ? p.b1[tid] : 0.f;
+    if (PAIR) lds_b[320 + tid] = p.b3a[tid] + (MODE == 2 ? p.bd[tid] : 0.f);
     __syncthreads();
 
     const int ngroups = (p.npix + 127) / 128;
@@ -84,11 +93,12 @@ __global__ __launch_bounds__(256, 2) void junction_kernel(const JuncParams p)
         const bool valid = pix < p.npix;
         const size_t px = valid ? pix : 0;
         // ---- loads: pixel fragments (B operands) first
-        u32x4 bt[4], bx[HAS_DS ? 4 : 1];
+        u32x4 bt[4], bx[HAS_DS ? 4 : 1], bta[PAIR ? 4 : 1];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bt[s] = *reinterpret_cast<const u32x4 *>(p.t2 + px * p.t2_cs + s * 16 + h * 8);
             if (HAS_DS) bx[s] = *reinterpret_cast<const u32x4 *>(p.x + px * p.x_cs + s * 16 + h * 8);
+            if (PAIR) bta[s] = *reinterpret_cast<const u32x4 *>(p.t2a + px * p.t2a_cs + s * 16 + h * 8);
         }
         // ---- GEMM 1 in two halves of 128 output channels (64 accumulator registers live at a time):
         //      y[256] = W3 t2 (+ Wd x) + shift (+ residual), ReLU, bf16; y leaves for HBM and stays in registers (yf) as the
@@ -96,21 +106,47 @@ __global__ __launch_bounds__(256, 2) void junction_kernel(const JuncParams p)
         u32x4 yf[8][2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            u32x4 rv[HAS_DS ? 1 : 4][2];
-            if (!HAS_DS)
+            u32x4 rv[4][2];  // the residual of this unit: from memory (MODE 0), or the previous unit's y made here (PAIR)
+            if (MODE == 0 || MODE == 3)
 #pragma unroll
                 for (int mm = 0; mm < 4; ++mm)
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                         rv[mm][q] = *reinterpret_cast<const u32x4 *>(p.res + px * p.res_cs + (half * 4 + mm) * 32 + q * 16 + h * 8);
             f32x16 acc[4];
+            auto init_acc = [&](int boff) {
 #pragma unroll
-            for (int mm = 0; mm < 4; ++mm)
+                for (int mm = 0; mm < 4; ++mm)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(lds_b + (half * 4 + mm) * 32 + 8 * gq + 4 * h);
-                    acc[mm][4 * gq + 0] = bv.x; acc[mm][4 * gq + 1] = bv.y; acc[mm][4 * gq + 2] = bv.z; acc[mm][4 * gq + 3] = bv.w;
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 bv = *reinterpret_cast<const float4 *>(lds_b + boff + (half * 4 + mm) * 32 + 8 * gq + 4 * h);
+                        acc[mm][4 * gq + 0] = bv.x; acc[mm][4 * gq + 1] = bv.y; acc[mm][4 * gq + 2] = bv.z; acc[mm][4 * gq + 3] = bv.w;
+                    }
+            };
+            if (PAIR) {  // the previous unit's y for these 128 channels: W3a t2a (+ Wd x) + shift (+ its residual), ReLU, bf16
+                init_acc(320);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int mm = 0; mm < 4; ++mm) {
+                        const int m = half * 4 + mm;
+                        const int unit = (((m >> 1) * 2 + (s >> 1)) * 4 + (s & 1) * 2 + h) * 64 + (m & 1) * 32 + r;
+                        const u32x4 a = *reinterpret_cast<const u32x4 *>(lds_w3a + unit * 16);
+                        acc[mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bta[s]), acc[mm], 0, 0, 0);
+                        if (MODE == 2) {
+                            const u32x4 ad = *reinterpret_cast<const u32x4 *>(lds_wd + unit * 16);
+                            acc[mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ad), __builtin_bit_cast(bf16x8, bx[s]), acc[mm], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) {
+                    if (MODE == 3) add_rows16(acc[mm], rv[mm]);
+                    pack_rows16(acc[mm], rv[mm]);  // (rv now holds what the previous junction would have stored)
+                }
+            }
+            init_acc(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -119,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void junction_kernel(const JuncParams p)
                     const int unit = (((m >> 1) * 2 + (s >> 1)) * 4 + (s & 1) * 2 + h) * 64 + (m & 1) * 32 + r;
                     const u32x4 a = *reinterpret_cast<const u32x4 *>(lds_w3 + unit * 16);
                     acc[mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bt[s]), acc[mm], 0, 0, 0);
-                    if (HAS_DS) {
+                    if (MODE == 1) {
                         const u32x4 ad = *reinterpret_cast<const u32x4 *>(lds_wd + unit * 16);
                         acc[mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ad), __builtin_bit_cast(bf16x8, bx[s]), acc[mm], 0, 0, 0);
                     }
@@ -129,9 +165,9 @@ __global__ __launch_bounds__(256, 2) void junction_kernel(const JuncParams p)
 #pragma unroll
             for (int mm = 0; mm < 4; ++mm) {
                 const int m = half * 4 + mm;
-                if (!HAS_DS) add_rows16(acc[mm], rv[mm]);
+                if (MODE != 1) add_rows16(acc[mm], rv[mm]);
                 pack_rows16(acc[mm], yf[m]);
-                if (valid) {
+                if (valid && p.y) {
                     bf16_raw *dst = p.y + (size_t)pix * p.y_cs + m * 32 + h * 8;
                     *reinterpret_cast<u32x4 *>(dst) = yf[m][0];
                     *reinterpret_cast<u32x4 *>(dst + 16) = yf[m][1];
@@ -175,24 +211,35 @@ __global__ __launch_bounds__(256, 2) void junction_kernel(const JuncParams p)
 #endif
 }
 
-static size_t junc_lds(bool ds) { return (ds ? 2 : 1) * W3_BYTES + W1_BYTES + 320 * 4; }
+static size_t junc_lds(int mode)
+{
+    const bool ds = mode == 1 || mode == 2, pair = mode >= 2;
+    return ((ds ? 2 : 1) + (pair ? 1 : 0)) * W3_BYTES + W1_BYTES + 576 * 4;
+}
 
 hipError_t junction_init()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(junction_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)junc_lds(true));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(junction_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)junc_lds(false));
+    const void *fns[4] = {reinterpret_cast<const void *>(junction_kernel<0>), reinterpret_cast<const void *>(junction_kernel<1>),
+                          reinterpret_cast<const void *>(junction_kernel<2>), reinterpret_cast<const void *>(junction_kernel<3>)};
+    for (int m = 0; m < 4; ++m) {
+        hipError_t e = hipFuncSetAttribute(fns[m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)junc_lds(m));
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t junction_launch(const JuncParams &p, int num_cus, hipStream_t s)
 {
-    const bool ds = p.x != nullptr;
+    const bool ds = p.x != nullptr, pair = p.t2a != nullptr;
+    const int mode = pair ? (ds ? 2 : 3) : (ds ? 1 : 0);
     const int ngroups = (p.npix + 127) / 128;
-    const int per_cu = ds ? 1 : 2;  // 96 KB + vs 64 KB + of LDS
+    const int per_cu = mode == 0 ? 2 : 1;  // 64 KB + of LDS, or 96 .. 128 KB +
     const int grid = ngroups < num_cus * per_cu ? ngroups : num_cus * per_cu;
-    if (ds) HH_LAUNCH(junction_kernel<true>, dim3(grid), dim3(256), junc_lds(true), s, p);
-    else HH_LAUNCH(junction_kernel<false>, dim3(grid), dim3(256), junc_lds(false), s, p);
+    switch (mode) {
+    case 0: HH_LAUNCH(junction_kernel<0>, dim3(grid), dim3(256), junc_lds(0), s, p); break;
+    case 1: HH_LAUNCH(junction_kernel<1>, dim3(grid), dim3(256), junc_lds(1), s, p); break;
+    case 2: HH_LAUNCH(junction_kernel<2>, dim3(grid), dim3(256), junc_lds(2), s, p); break;
+    default: HH_LAUNCH(junction_kernel<3>, dim3(grid), dim3(256), junc_lds(3), s, p); break;
+    }
     return hipGetLastError();
 }

@@ -286,15 +286,21 @@ struct Builder {
         if (!stem_fused) conv(L(bb + ".conv2", bb + ".bn2", 64, 64, 3, 2), S1, X, 1);
 
         // stage 0: four Bottlenecks on one scale (hrnet.py:29-74), then the 256->C / 256->2C transition
-        const int t1 = T(64, 2), t2 = T(64, 2), Y = T(256, 2);
+        // bf16: the junctions work in pairs -- units 0 and 2 do not store their 256-channel y, units 1 and 3 make it again per pixel
+        // from the previous unit's t2 (two more 1x1 GEMMs) -- so conv2 alternates between two t2 tensors
+        // (HH_NO_JUNC_PAIR=1: every junction stores y and the next one reads it)
+        const bool jpair = n.dtype != 2 && !getenv("HH_NO_JUNC_PAIR");
+        const int t1 = T(64, 2), t2 = T(64, 2), t2b = jpair ? T(64, 2) : t2, Y = T(256, 2);
         // conv3 (+ downsample) of unit u and conv1 of unit u+1 are both 1x1: one junction kernel makes y and the next t1 in a
         // single pass over the 256-channel tensor (bottleneck_junction.hip)
         auto unit = [&](int u) { return bb + ".stages.0.blocks.0.scales_blocks.0." + std::to_string(u); };
         cb(unit(0), "conv1", "bn1", 64, 64, 1, 1, X, t1, 1);
         const int DS = n.dtype == 2 ? T(256, 2) : -1;  // fp8 path: the downsample branch of unit 0 is a tensor of its own
+        int prev_conv3 = -1, ds_layer = -1;
         for (int u = 0; u < 4; ++u) {
             const std::string up = unit(u);
-            cb(up, "conv2", "bn2", 64, 64, 3, 1, t1, t2, 1);
+            const int t2u = (u & 1) ? t2b : t2, t2p = (u & 1) ? t2 : t2b;  // this unit's / the previous unit's conv2 output
+            cb(up, "conv2", "bn2", 64, 64, 3, 1, t1, t2u, 1);
             if (n.dtype == 2) {  // layer by layer (hrnet.py:58-74): downsample, conv3 + residual + ReLU, next unit's conv1
                 if (u == 0) cb(up, "downsample.0", "downsample.1", 64, 256, 1, 1, X, DS, 0);
                 cb(up, "conv3", "bn3", 64, 256, 1, 1, t2, Y, 1, u == 0 ? DS : Y);
@@ -306,8 +312,15 @@ struct Builder {
             o.layer2 = u == 0 ? L(up + ".downsample.0", up + ".downsample.1", 64, 256, 1, 1) : -1;
             o.layer = L(up + ".conv3", up + ".bn3", 64, 256, 1, 1);
             o.layer3 = u < 3 ? L(unit(u + 1) + ".conv1", unit(u + 1) + ".bn1", 256, 64, 1, 1) : -1;
-            o.in = t2; o.in2 = u == 0 ? X : -1; o.res = u == 0 ? -1 : Y;
+            o.in = t2u; o.in2 = u == 0 ? X : -1; o.res = u == 0 ? -1 : Y;
             o.out = Y; o.out2 = u < 3 ? t1 : -1;
+            if (jpair && !(u & 1)) o.out = -1;  // units 0, 2: y is not stored
+            if (jpair && (u & 1)) {             // units 1, 3: the previous unit's y from its t2 (and, for unit 1, the downsample of x)
+                o.layer4 = prev_conv3; o.in3 = t2p;
+                if (u == 1) { o.layer2 = ds_layer; o.in2 = X; o.res = -1; }
+            }
+            if (u == 0) ds_layer = o.layer2;
+            prev_conv3 = o.layer;
             n.ops.push_back(o);
         }
         if (split0) {  // the chain above becomes half 0 on lane 0, a copy of it half 1 on lane 1
@@ -975,8 +988,12 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             if (op.res >= 0) { p.res = tensors[op.res].ptr + pix0 * tensors[op.res].C; p.res_cs = tensors[op.res].C; }
             if (op.in2 >= 0) { p.x = tensors[op.in2].ptr + pix0 * tensors[op.in2].C; p.x_cs = tensors[op.in2].C; p.wd = layers[op.layer2].d_w; p.bd = layers[op.layer2].d_bias; }
             p.w3 = l3.d_w; p.b3 = l3.d_bias;
+            if (op.layer4 >= 0) {
+                p.t2a = tensors[op.in3].ptr + pix0 * tensors[op.in3].C; p.t2a_cs = tensors[op.in3].C;
+                p.w3a = layers[op.layer4].d_w; p.b3a = layers[op.layer4].d_bias;
+            }
             if (op.layer3 >= 0) { p.w1 = layers[op.layer3].d_w; p.b1 = layers[op.layer3].d_bias; p.t1 = tensors[op.out2].ptr + pix0 * tensors[op.out2].C; p.t1_cs = tensors[op.out2].C; }
-            p.y = tensors[op.out].ptr + pix0 * tensors[op.out].C; p.y_cs = tensors[op.out].C;
+            if (op.out >= 0) { p.y = tensors[op.out].ptr + pix0 * tensors[op.out].C; p.y_cs = tensors[op.out].C; }
             p.npix = B * (H >> ti.shift) * (W >> ti.shift);
             ProfRecord *pr = nullptr;
             if (prof_enabled) {
@@ -989,9 +1006,11 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr = &prof[prof_used++];
                 pr->op = (int)(&op - ops.data());
                 pr->cfg = HH_CFG_JUNCTION;
-                pr->flops = 2.0 * p.npix * 64.0 * 256.0 * (1 + (op.in2 >= 0) + (op.layer3 >= 0));
-                pr->bytes = 2.0 * p.npix * (64 + (op.in2 >= 0 ? 64 : 256) + 256 + (op.layer3 >= 0 ? 64 : 0)) +
-                            2.0 * 64 * 256 * (1 + (op.in2 >= 0) + (op.layer3 >= 0));
+                pr->flops = 2.0 * p.npix * 64.0 * 256.0 * (1 + (op.in2 >= 0 && op.layer4 < 0) + (op.layer3 >= 0));
+                // (algorithmic: what the unit needs when every junction stores y and reads the previous one -- the pair mode's savings
+                // and its extra GEMMs are the implementation's business)
+                pr->bytes = 2.0 * p.npix * (64 + ((op.in2 >= 0 && op.layer4 < 0) ? 64 : 256) + 256 + (op.layer3 >= 0 ? 64 : 0)) +
+                            2.0 * 64 * 256 * (1 + (op.in2 >= 0 && op.layer4 < 0) + (op.layer3 >= 0));
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
                 if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 4 * pr->slot;
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
@@ -1231,7 +1250,7 @@ int hh_net::check_plan(std::string *why) const
         case OP_CONV: rd = {op.in, op.res, op.in2, op.in3}; wr = {op.out}; break;
         case OP_UPADD: rd = {op.in, op.up[0], op.up[1], op.up[2]}; wr = {op.out}; break;
         case OP_BB: rd = {op.in}; wr = {op.out}; break;
-        case OP_JUNC: rd = {op.in, op.in2, op.res}; wr = {op.out, op.out2}; break;
+        case OP_JUNC: rd = {op.in, op.in2, op.res, op.in3}; wr = {op.out, op.out2}; break;
         case OP_STEM: wr = {op.out}; break;
         case OP_TAP: continue;  // taps only run with the lanes switched off (enqueue: multi = ... && !taps_enabled)
         case OP_AVGPOOL: rd = {op.in}; break;
@@ -1294,7 +1313,7 @@ double hh_net::flops(int B, int H, int W) const
         }
         if (op.kind == OP_JUNC) {
             const TensorDesc &ti = tensors[op.in];
-            macs += (double)(H >> ti.shift) * (W >> ti.shift) * 64.0 * 256.0 * (1 + (op.in2 >= 0) + (op.layer3 >= 0));
+            macs += (double)(H >> ti.shift) * (W >> ti.shift) * 64.0 * 256.0 * (1 + (op.in2 >= 0 && op.layer4 < 0) + (op.layer3 >= 0));
             continue;
         }
         if (op.kind != OP_CONV) continue;

@@ -64,6 +64,7 @@ struct Op {
     OpKind kind = OP_CONV;
     int layer = -1, layer2 = -1;  // layer2: second conv of a fused BasicBlock / downsample conv of a junction (-1: none)
     int layer3 = -1;              // OP_JUNC: first conv of the next Bottleneck (-1: none)
+    int layer4 = -1;              // OP_JUNC, pair mode: conv3 of the PREVIOUS Bottleneck, whose output is made again from in3 (= its t2) instead of read
     int in2 = -1, out2 = -1;      // OP_JUNC: downsample input x, and the t1 output
     int in3 = -1;                 // OP_CONV over concatenated inputs: in, in2, in3 (ConvLayer::mcin channels each)
     int in = -1, in_coff = 0;

@@ -181,9 +181,11 @@ struct JuncParams {
     const bf16_raw *t2; int t2_cs;     // [npix, 64]  conv2 output of this unit
     const bf16_raw *res; int res_cs;   // [npix, 256] previous y (units 1-3), or nullptr
     const bf16_raw *x; int x_cs;       // [npix, 64]  unit-0 input of the downsample conv, or nullptr
+    const bf16_raw *t2a; int t2a_cs;   // pair mode: conv2 output of the PREVIOUS unit, whose y is made again here instead of read (else nullptr)
+    const bf16_raw *w3a; const float *b3a;  // pair mode: the previous unit's conv3 (its downsample, if it is unit 0, is wd / bd with x)
     const bf16_raw *w3, *wd, *w1;      // packed as the conv_mfma family packs 1x1 KC=32 NT=2 layers; wd / w1 may be nullptr
     const float *b3, *bd, *b1;
-    bf16_raw *y; int y_cs;             // [npix, 256]
+    bf16_raw *y; int y_cs;             // [npix, 256]; nullptr: not stored (the next junction makes it again, pair mode)
     bf16_raw *t1; int t1_cs;           // [npix, 64] (only when w1)
     int npix;
     unsigned long long *clk;           // optional {min start, max end} device-clock probe

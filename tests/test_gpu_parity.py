@@ -172,12 +172,13 @@ def test_stage0_part_batches_opt_in(pkg):
 
 def test_schedule_and_fusion_switches(pkg, net_golden):
     """The plan variants behind the engine switches: all-to-all joins (HH_FULL_JOIN=1) give the default plan's bits (same kernels,
-    other edges); one launch per summed stride-2 conv (HH_NO_FUSION_MERGE=1) rounds the partial sums to bf16 between the launches
+    other edges), and so do stage-0 junctions that each store their y (HH_NO_JUNC_PAIR=1: the pair mode makes the previous
+    unit's y again with the same arithmetic and the same bf16 rounding); one launch per summed stride-2 conv (HH_NO_FUSION_MERGE=1) rounds the partial sums to bf16 between the launches
     and so differs from the merged conv by bf16 noise only; both meet the golden tolerance."""
     x = torch.from_numpy(pkg.synth.synth_images(2, 128, 128, 1)).to(DEV)
     base, _ = _net(pkg, 32, 1)
     ref = [t.clone() for t in base.forward_raw(x)]
-    for env, exact in ((("HH_FULL_JOIN", "1"), True), (("HH_NO_FUSION_MERGE", "1"), False)):
+    for env, exact in ((("HH_FULL_JOIN", "1"), True), (("HH_NO_FUSION_MERGE", "1"), False), (("HH_NO_JUNC_PAIR", "1"), True)):
         os.environ[env[0]] = env[1]
         try:
             net, _ = _net(pkg, 32, 1)
