@@ -60,36 +60,43 @@ constexpr int W1_BYTES = 64 * 256 * 2;  // next conv1: packed [chunk 8][c8 4][64
 // weights p.w3a) -- MODE 2: the previous unit is unit 0 (+ downsample of x), MODE 3: a plain unit on top of p.res -- and used,
 // rounded to bf16 exactly as it would have been stored, as the residual of this unit.  The previous junction then does not
 // store its y at all (p.y == nullptr there): stage 0 moves a quarter less through HBM for two more 1x1 GEMMs per pair.
+// Workgroups: eight waves per CU where the registers allow it -- MODE 0 (64 KB of weights) and MODE 3 without a next conv1 (64 KB)
+// as two workgroups of 256 threads, MODE 1 (96 KB) as one of 512 (81 -> 58 us); MODE 2 (128 KB, 241 registers) and MODE 3 with a
+// next conv1 stay at one workgroup of 256 threads: with 512 they spill (149 -> 185 us).
 template <int MODE>
-__global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void junction_kernel(const JuncParams p)
+__global__ __launch_bounds__(MODE == 1 ? 512 : 256, (MODE == 0 || MODE == 3) ? 2 : 1) void junction_kernel(const JuncParams p)
 {
+    constexpr int NT = MODE == 1 ? 512 : 256;
     constexpr bool HAS_DS = MODE == 1 || MODE == 2, PAIR = MODE >= 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *lds_w3 = smem;                                           // this unit's conv3
     char *lds_wd = smem + W3_BYTES;                                // only when HAS_DS
     char *lds_w3a = smem + (HAS_DS ? 2 : 1) * W3_BYTES;            // only when PAIR: the previous unit's conv3
     char *lds_w1 = smem + ((HAS_DS ? 2 : 1) + (PAIR ? 1 : 0)) * W3_BYTES;
-    float *lds_b = reinterpret_cast<float *>(lds_w1 + W1_BYTES);   // [256] y shift, [64] t1 shift, [256] previous y shift (PAIR)
+    float *lds_b = reinterpret_cast<float *>(lds_w1 + (p.w1 ? W1_BYTES : 0));  // [256] y shift, [64] t1 shift, [256] previous y shift (PAIR)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
 #ifndef HH_NO_CLK
     if (p.clk && tid == 0) atomicMin(p.clk, wall_clock64());
 #endif
-    for (int u = tid; u < W3_BYTES / 16; u += 256) {
+    for (int u = tid; u < W3_BYTES / 16; u += NT) {
         reinterpret_cast<u32x4 *>(lds_w3)[u] = reinterpret_cast<const u32x4 *>(p.w3)[u];
         if (HAS_DS) reinterpret_cast<u32x4 *>(lds_wd)[u] = reinterpret_cast<const u32x4 *>(p.wd)[u];
         if (PAIR) reinterpret_cast<u32x4 *>(lds_w3a)[u] = reinterpret_cast<const u32x4 *>(p.w3a)[u];
         if (p.w1) reinterpret_cast<u32x4 *>(lds_w1)[u] = reinterpret_cast<const u32x4 *>(p.w1)[u];
     }
     // the downsample shift belongs to the unit the downsample conv belongs to: this one (MODE 1) or the previous one (MODE 2)
-    lds_b[tid] = p.b3[tid] + (MODE == 1 ? p.bd[tid] : 0.f);
-    if (tid < 64) lds_b[256 + tid] = p.w1 ? p.b1[tid] : 0.f;
-    if (PAIR) lds_b[320 + tid] = p.b3a[tid] + (MODE == 2 ? p.bd[tid] : 0.f);
+    if (tid < 256) {
+        lds_b[tid] = p.b3[tid] + (MODE == 1 ? p.bd[tid] : 0.f);
+        if (tid < 64) lds_b[256 + tid] = p.w1 ? p.b1[tid] : 0.f;
+        if (PAIR) lds_b[320 + tid] = p.b3a[tid] + (MODE == 2 ? p.bd[tid] : 0.f);
+    }
     __syncthreads();
 
-    const int ngroups = (p.npix + 127) / 128;
+    constexpr int GP = NT / 2;  // pixels per workgroup step: 32 per wave
+    const int ngroups = (p.npix + GP - 1) / GP;
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const int pix = g * 128 + wave * 32 + r;
+        const int pix = g * GP + wave * 32 + r;
         const bool valid = pix < p.npix;
         const size_t px = valid ? pix : 0;
         // ---- loads: pixel fragments (B operands) first
@@ -211,10 +218,10 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void junction_kernel(const 
 #endif
 }
 
-static size_t junc_lds(int mode)
+static size_t junc_lds(int mode, bool w1 = true)
 {
     const bool ds = mode == 1 || mode == 2, pair = mode >= 2;
-    return ((ds ? 2 : 1) + (pair ? 1 : 0)) * W3_BYTES + W1_BYTES + 576 * 4;
+    return ((ds ? 2 : 1) + (pair ? 1 : 0)) * W3_BYTES + (w1 ? W1_BYTES : 0) + 576 * 4;
 }
 
 hipError_t junction_init()
@@ -232,14 +239,16 @@ hipError_t junction_launch(const JuncParams &p, int num_cus, hipStream_t s)
 {
     const bool ds = p.x != nullptr, pair = p.t2a != nullptr;
     const int mode = pair ? (ds ? 2 : 3) : (ds ? 1 : 0);
-    const int ngroups = (p.npix + 127) / 128;
-    const int per_cu = mode == 0 ? 2 : 1;  // 64 KB + of LDS, or 96 .. 128 KB +
+    const int nthr = mode == 1 ? 512 : 256;
+    const int ngroups = (p.npix + nthr / 2 - 1) / (nthr / 2);
+    const size_t lds = junc_lds(mode, p.w1 != nullptr);
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     const int grid = ngroups < num_cus * per_cu ? ngroups : num_cus * per_cu;
     switch (mode) {
-    case 0: HH_LAUNCH(junction_kernel<0>, dim3(grid), dim3(256), junc_lds(0), s, p); break;
-    case 1: HH_LAUNCH(junction_kernel<1>, dim3(grid), dim3(256), junc_lds(1), s, p); break;
-    case 2: HH_LAUNCH(junction_kernel<2>, dim3(grid), dim3(256), junc_lds(2), s, p); break;
-    default: HH_LAUNCH(junction_kernel<3>, dim3(grid), dim3(256), junc_lds(3), s, p); break;
+    case 0: HH_LAUNCH(junction_kernel<0>, dim3(grid), dim3(256), lds, s, p); break;
+    case 1: HH_LAUNCH(junction_kernel<1>, dim3(grid), dim3(512), lds, s, p); break;
+    case 2: HH_LAUNCH(junction_kernel<2>, dim3(grid), dim3(256), lds, s, p); break;
+    default: HH_LAUNCH(junction_kernel<3>, dim3(grid), dim3(256), lds, s, p); break;
     }
     return hipGetLastError();
 }
