@@ -18,6 +18,10 @@ model = pkg.InferenceKeypointsModel(net, det_thr=0.05, tag_thr=0.5, use_flip=fli
 rs = np.random.RandomState(0)
 images = [rs.randint(0, 255, (512, 512, 3)).astype(np.uint8) for _ in range(n)] if garbage else pkg.synth.synth_passthrough_raw_u8(64, 128, 128, 10, 17, 0) * (n // 64)
 model.infer_images(images[:64])
+if os.environ.get("API_PROFILE"):  # where the host time of the batched path goes (API_PROFILE=1)
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable(); model.infer_images(images); torch.cuda.synchronize(); pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 res = model.infer_images(images)
 torch.cuda.synchronize(); t1 = time.perf_counter() - t0
