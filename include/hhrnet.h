@@ -136,6 +136,17 @@ int hh_tap_read(hh_net *net, int index, float *host_nchw);        /* synchronous
 int hh_preprocess_u8(const unsigned char *image_hwc, int h, int w, const double dst_to_src[6], float *out_nchw, int H, int W,
                      const float mean[3], const float stdv[3], void *stream);
 
+/* The same for a batch of raw images of any sizes in ONE launch (the batched caller behind the reference's per-image `__call__`,
+ * bin/eval.py:18-49): the images lie in one device buffer, image i at `images_base + descs[i].offset` with its own size and affine;
+ * `descs_dev` is a DEVICE array (the caller ships it with the pixels in the same host->device copy); out_nchw is [n,3,H,W]. */
+typedef struct hh_image_desc {
+    long long offset;     /* bytes from images_base */
+    int h, w;             /* raw image size */
+    double dst_to_src[6]; /* as in hh_preprocess_u8 */
+} hh_image_desc;
+int hh_preprocess_u8_batch(const unsigned char *images_base, const hh_image_desc *descs_dev, int n, float *out_nchw, int H, int W,
+                           const float mean[3], const float stdv[3], void *stream);
+
 /* Flip test-time augmentation, keypoints/model.py:85-94 (COCO_FLIP_INDEX: keypoints/transforms.py:11).
  * hh_flip_images: out = flip(images, W axis), fp32 NCHW.
  * hh_flip_merge : hm[b,k] = (hm[b,k] + flip_w(hm_flipped[b, perm[k]])) / 2  in place for `hm`

@@ -66,6 +66,7 @@ def _sig(lib):
         "hh_debug_bb_bench": (i32, [i32, i32, i32, i32, C.POINTER(C.c_float), vp]),
         "hh_debug_bb_compare": (i32, [i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "hh_preprocess_u8": (i32, [vp, i32, i32, C.POINTER(C.c_double), vp, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
+        "hh_preprocess_u8_batch": (i32, [vp, vp, i32, vp, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
         "hh_flip_images": (i32, [vp, vp, i32, i32, i32, i32, vp]),
         "hh_flip_merge": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp]),
         "hh_decoder_create": (vp, [i32, i32, dbl, dbl]),

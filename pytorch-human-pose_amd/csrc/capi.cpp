@@ -175,6 +175,16 @@ int hh_preprocess_u8(const unsigned char *image_hwc, int h, int w, const double 
     return 0;
 }
 
+int hh_preprocess_u8_batch(const unsigned char *images_base, const hh_image_desc *descs_dev, int n, float *out_nchw, int H, int W,
+                           const float mean[3], const float stdv[3], void *stream)
+{
+    static_assert(sizeof(hh_image_desc) == sizeof(HHImageDesc) && sizeof(HHImageDesc) == 64, "descriptor layout");
+    if (!images_base || !descs_dev || !out_nchw || n <= 0 || n > 65535 || H <= 0 || W <= 0) { hh_set_error("hh_preprocess_u8_batch: bad argument"); return 1; }
+    HH_CHECK_HIP(launch_preprocess_batch(images_base, reinterpret_cast<const HHImageDesc *>(descs_dev), n, out_nchw, H, W, mean, stdv,
+                                         (hipStream_t)stream));
+    return 0;
+}
+
 int hh_loss_heatmaps(const float *pred, int64_t pred_bstride, const float *target, const float *mask, int B, int K, int h, int w,
                      float *loss, float *grad, int64_t grad_bstride, double *scratch, void *stream)
 {

@@ -250,6 +250,13 @@ hipError_t launch_upadd_fp8(const UpAddFp8Params &p, hipStream_t s);
 hipError_t launch_avgpool(const bf16_raw *in, int in_cs, float *out, int B, int HW, int C, hipStream_t s);
 hipError_t launch_linear(const float *x, const float *w, const float *bias, float *y, int B, int K, int N, hipStream_t s);
 
+struct HHImageDesc {  // one raw image of a batch (hh_image_desc of include/hhrnet.h): 64 bytes
+    long long offset;  // bytes from the batch's base pointer to the image's first pixel
+    int h, w;
+    double inv[6];     // destination -> source affine
+};
+hipError_t launch_preprocess_batch(const unsigned char *base, const HHImageDesc *descs, int n, float *out, int H, int W,
+                                   const float mean[3], const float stdv[3], hipStream_t s);
 hipError_t launch_preprocess(const unsigned char *img, int h, int w, const double inv[6], float *out, int H, int W,
                              const float mean[3], const float stdv[3], hipStream_t s);
 hipError_t launch_flip_images(const float *in, float *out, int B, int C, int H, int W, hipStream_t s);

@@ -270,18 +270,14 @@ hipError_t launch_linear(const float *x, const float *w, const float *bias, floa
 // inverse-mapped bilinear affine warp of a uint8 HWC image with a constant-0 border, rounded to uint8 like
 // cv2.warpAffine's output, then ToTensor (/255) and Normalize -> fp32 NCHW.  float64 coordinates/weights so the
 // result is identical to keypoints/transforms_utils.py::warp_affine (the host restatement).
-__global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char *__restrict__ img, int h, int w, double i00, double i01,
-                                                         double i02, double i10, double i11, double i12, float *__restrict__ out,
-                                                         int H, int W, float m0, float m1, float m2, float s0, float s1, float s2)
+__device__ __forceinline__ void preprocess_pixel(const unsigned char *__restrict__ img, int h, int w, const double inv[6],
+                                                 float *__restrict__ out, int H, int W, int i, const float mean[3], const float stdv[3])
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= H * W) return;
     const int y = i / W, x = i % W;
-    const double sx = i00 * x + i01 * y + i02, sy = i10 * x + i11 * y + i12;
+    const double sx = inv[0] * x + inv[1] * y + inv[2], sy = inv[3] * x + inv[4] * y + inv[5];
     const double fx0 = floor(sx), fy0 = floor(sy);
     const long x0 = (long)fx0, y0 = (long)fy0;
     const double fx = sx - fx0, fy = sy - fy0;
-    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         auto tap = [&](long yy, long xx) -> double {
@@ -291,6 +287,34 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char *__
         const float u8 = (float)fmin(fmax(rint(v), 0.0), 255.0);
         out[(size_t)c * H * W + i] = (u8 / 255.0f - mean[c]) / stdv[c];
     }
+}
+__global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char *__restrict__ img, int h, int w, double i00, double i01,
+                                                         double i02, double i10, double i11, double i12, float *__restrict__ out,
+                                                         int H, int W, float m0, float m1, float m2, float s0, float s1, float s2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const double inv[6] = {i00, i01, i02, i10, i11, i12};
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    preprocess_pixel(img, h, w, inv, out, H, W, i, mean, stdv);
+}
+// a batch of raw images of any sizes into one [n,3,H,W] tensor: blockIdx.y = image, its descriptor read from device memory
+__global__ __launch_bounds__(256) void preprocess_batch_kernel(const unsigned char *__restrict__ base, const HHImageDesc *__restrict__ descs,
+                                                               float *__restrict__ out, int H, int W, float m0, float m1, float m2,
+                                                               float s0, float s1, float s2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const HHImageDesc d = descs[blockIdx.y];
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    preprocess_pixel(base + d.offset, d.h, d.w, d.inv, out + (size_t)blockIdx.y * 3 * H * W, H, W, i, mean, stdv);
+}
+hipError_t launch_preprocess_batch(const unsigned char *base, const HHImageDesc *descs, int n, float *out, int H, int W,
+                                   const float mean[3], const float stdv[3], hipStream_t s)
+{
+    hipLaunchKernelGGL(preprocess_batch_kernel, dim3((H * W + 255) / 256, n), dim3(256), 0, s, base, descs, out, H, W, mean[0], mean[1],
+                       mean[2], stdv[0], stdv[1], stdv[2]);
+    return hipGetLastError();
 }
 hipError_t launch_preprocess(const unsigned char *img, int h, int w, const double inv[6], float *out, int H, int W,
                              const float mean[3], const float stdv[3], hipStream_t s)

@@ -404,6 +404,30 @@ def test_gpu_preprocessing_matches_host_restatement(pkg):
         assert tuple(center) == tuple(c2) and tuple(scale) == tuple(s2)
         assert x.shape[1:] == (3,) + resized.shape[:2]
         assert np.array_equal(x[0].cpu().numpy(), np.ascontiguousarray(ref.transpose(2, 0, 1)))
+    # hh_preprocess_u8_batch: raw images of different sizes (one aspect ratio -> one model-input shape) in one launch, descriptors
+    # read from device memory: the same bits as image by image
+    import ctypes as C
+    mod = importlib.import_module(pkg.__name__ + ".keypoints.model")
+    imgs = [np.random.RandomState(s).randint(0, 256, shp).astype(np.uint8) for s, shp in ((1, (200, 300, 3)), (2, (400, 600, 3)), (3, (100, 150, 3)))]
+    singles = [model.prepare_input(im)[0] for im in imgs]
+    assert len({tuple(t.shape) for t in singles}) == 1
+    H, W = singles[0].shape[-2:]
+    offs = np.cumsum([0] + [im.size for im in imgs])
+    desc_off = (int(offs[-1]) + 63) // 64 * 64
+    buf = np.zeros(desc_off + 64 * len(imgs), np.uint8)
+    descs = buf[desc_off:].view(mod._IMAGE_DESC)
+    for j, im in enumerate(imgs):
+        buf[offs[j]:offs[j + 1]] = im.reshape(-1)
+        descs[j] = (int(offs[j]), im.shape[0], im.shape[1], model._geometry(im)[3].reshape(6))
+    raw = torch.from_numpy(buf).to(DEV)
+    out = torch.empty((len(imgs), 3, H, W), device=DEV)
+    lib = pkg._lib.load()
+    fp = C.POINTER(C.c_float)
+    pkg._lib.check(lib.hh_preprocess_u8_batch(raw.data_ptr(), raw.data_ptr() + desc_off, len(imgs), out.data_ptr(), H, W,
+                                              tu.IMAGENET_MEAN.ctypes.data_as(fp), tu.IMAGENET_STD.ctypes.data_as(fp),
+                                              torch.cuda.current_stream().cuda_stream))
+    for j, t in enumerate(singles):
+        assert torch.equal(out[j], t[0])
 
 
 def test_resize_accumulate_and_multi_scale_extension(pkg):

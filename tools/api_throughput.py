@@ -6,7 +6,7 @@ import importlib, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("pytorch-human-pose_amd")
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 flip = len(sys.argv) > 2 and sys.argv[2] == "flip"
 net = pkg.HigherHRNet(17, 32)
 garbage = len(sys.argv) > 3 and sys.argv[3] == "garbage"  # plain random weights: every candidate passes det_thr (decode worst case)
@@ -17,11 +17,35 @@ else:  # pass-through weights: the maps hold the ~10 people encoded in each imag
 model = pkg.InferenceKeypointsModel(net, det_thr=0.05, tag_thr=0.5, use_flip=flip, input_size=512, device="cuda:0")
 rs = np.random.RandomState(0)
 images = [rs.randint(0, 255, (512, 512, 3)).astype(np.uint8) for _ in range(n)] if garbage else pkg.synth.synth_passthrough_raw_u8(64, 128, 128, 10, 17, 0) * (n // 64)
-model.infer_images(images[:64])
+model.infer_images(images)  # (the same list: the caching allocator then holds every block the timed call needs)
 if os.environ.get("API_PROFILE"):  # where the host time of the batched path goes (API_PROFILE=1)
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable(); model.infer_images(images); torch.cuda.synchronize(); pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+if os.environ.get("API_PHASES"):  # wall time of the host phases of the batched path, without a profiler's overhead
+    acc = {"sync": 0.0, "nsync": 0}
+    ev_sync, fwd, dec = torch.cuda.Event.synchronize, model.forward_tta, model._parser.decode_batch_device
+    marks = []
+    def sync(self):
+        t = time.perf_counter(); ev_sync(self); acc["sync"] += time.perf_counter() - t; acc["nsync"] += 1
+    def forward_tta(x):
+        e0 = torch.cuda.Event(enable_timing=True); e0.record(); marks.append([e0]); return fwd(x)
+    def decode(*a, **k):
+        r = dec(*a, **k); e1 = torch.cuda.Event(enable_timing=True); e1.record(); marks[-1].append(e1); return r
+    torch.cuda.Event.synchronize, model.forward_tta, model._parser.decode_batch_device = sync, forward_tta, decode
+    a0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = model.infer_images(images); res = None
+    torch.cuda.synchronize(); tt = time.perf_counter() - t0
+    nb = n / 32
+    print(f"phases per batch of 32 (ms): total {tt / nb * 1e3:.2f}, event waits {acc['sync'] / nb * 1e3:.2f} ({acc['nsync']} waits), "
+          f"host work {(tt - acc['sync']) / nb * 1e3:.2f}; device allocations {torch.cuda.memory_stats().get('num_device_alloc', 0) - a0}")
+    torch.cuda.Event.synchronize, model.forward_tta, model._parser.decode_batch_device = ev_sync, fwd, dec
+    busy = [a.elapsed_time(b) for a, b in marks]
+    gap = [marks[i][1].elapsed_time(marks[i + 1][0]) for i in range(len(marks) - 1)]
+    print(f"device, per batch (ms): forward + decode {np.median(busy):.2f} (median; max {max(busy):.2f}), "
+          f"from there to the next batch's forward {np.median(gap):.2f} (median; max {max(gap):.2f})")
+# (a result keeps its batch's input tensor and maps alive, like the reference's: ~10 MB of device memory per image until dropped)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 res = model.infer_images(images)
 torch.cuda.synchronize(); t1 = time.perf_counter() - t0
