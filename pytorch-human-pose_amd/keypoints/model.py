@@ -175,7 +175,10 @@ class InferenceKeypointsModel:
         self._lib = _lib.load()
         self._parser = MPPEHeatmapParser(net.num_kpts, max_num_people, det_thr, tag_thr)
         self._perm = np.asarray(COCO_FLIP_INDEX, np.int32)
-        self._stream = None
+        self._stream = None       # highest-priority compute stream (created on first use: needs the device)
+        self._copy_stream = None  # infer_images: host -> device of the next batch's pixels
+        self._d2h_stream = None   # infer_images: result copies, beside the next batch's launches
+        self._out_ring: dict = {}  # infer_images: pinned result buffers per pipeline slot and shape
         if ckpt_path is not None:
             self.load_checkpoint(ckpt_path)
 
@@ -368,7 +371,7 @@ class InferenceKeypointsModel:
 
                 # host -> device on a copy stream of its own, so that the pixels of this batch cross PCIe while the previous
                 # batch still computes (25 MB per batch of 32 512x512 images: ~1.7 ms that would otherwise sit on the compute stream)
-                if getattr(self, "_copy_stream", None) is None:
+                if self._copy_stream is None:
                     self._copy_stream = torch.cuda.Stream(self.device)
                     # (the priority of the compute stream: at a lower one the result copies would wait for the whole next batch)
                     self._d2h_stream = torch.cuda.Stream(self.device, priority=torch.cuda.Stream.priority_range()[1])
@@ -390,7 +393,7 @@ class InferenceKeypointsModel:
                     # device -> host into pinned buffers kept per pipeline slot (allocating pinned memory costs ~0.4 ms per array);
                     # finish() of this slot's previous batch ran before this point and copied what it keeps
                     key = (turn, tuple((tuple(t.shape), t.dtype) for t in out))
-                    ring = self.__dict__.setdefault("_out_ring", {})
+                    ring = self._out_ring
                     if key not in ring:
                         ring[key] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out]
                     # ... on a stream of their own behind the decode, so that the next batch's launches do not queue behind them
