@@ -613,7 +613,9 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int l)
 }
 
 // -> 0 and `star` = the starred column of row `lane` (-1: none), or 1 if the iteration guard ran out
-__device__ int munkres_wave(MatchShared &S, int n, int lane, int &star)
+// NMAX >= n: the length of the unrolled column loops (the column of lane j lives in NMAX registers)
+template <int NMAX>
+__device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
 {
     // step 1: subtract the row minimum (lane = row, on the LDS copy)
     if (lane < n) {
@@ -622,10 +624,10 @@ __device__ int munkres_wave(MatchShared &S, int n, int lane, int &star)
         for (int j = 0; j < n; ++j) S.Cm[lane * MLD + j] -= mn;
     }
     __syncthreads();
-    double col[HH_MAX_PEOPLE];  // column `lane`
+    double col[NMAX];  // column `lane`
     u64 myz = 0;                // zeros of row `lane`
 #pragma unroll
-    for (int i = 0; i < HH_MAX_PEOPLE; ++i) {
+    for (int i = 0; i < NMAX; ++i) {
         col[i] = 1.0;
         if (i < n) {
             if (lane < n) col[i] = S.Cm[i * MLD + lane];
@@ -695,7 +697,7 @@ __device__ int munkres_wave(MatchShared &S, int n, int lane, int &star)
             double mn = 9223372036854775807.0;
             const bool cu = lane < n && !((ccm >> lane) & 1);
 #pragma unroll
-            for (int i = 0; i < HH_MAX_PEOPLE; ++i)
+            for (int i = 0; i < NMAX; ++i)
                 if (i < n && cu && !((rcm >> i) & 1) && mn > col[i]) mn = col[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -703,7 +705,7 @@ __device__ int munkres_wave(MatchShared &S, int n, int lane, int &star)
                 mn = o < mn ? o : mn;
             }
 #pragma unroll
-            for (int i = 0; i < HH_MAX_PEOPLE; ++i)
+            for (int i = 0; i < NMAX; ++i)
                 if (i < n) {
                     double c = col[i];
                     if ((rcm >> i) & 1) c += mn;
@@ -716,6 +718,15 @@ __device__ int munkres_wave(MatchShared &S, int n, int lane, int &star)
         }
     }
     return 1;
+}
+
+// most images hold far fewer than HH_MAX_PEOPLE candidates per joint: the short instantiations skip the masked-off iterations
+__device__ __forceinline__ int munkres_wave(MatchShared &S, int n, int lane, int &star)
+{
+    if (n <= 8) return munkres_wave_n<8>(S, n, lane, star);
+    if (n <= 16) return munkres_wave_n<16>(S, n, lane, star);
+    if (n <= 24) return munkres_wave_n<24>(S, n, lane, star);
+    return munkres_wave_n<HH_MAX_PEOPLE>(S, n, lane, star);
 }
 
 __constant__ int c_joints_order[17] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 7, 8, 9, 10, 13, 14, 15, 16};  // grouping.py:63-65
