@@ -969,8 +969,16 @@ __global__ __launch_bounds__(64) void refine_mean_kernel(const DecodeSrc src, in
 }
 
 // (1b) per (b,k) quarter-res cell: [lo, hi] of the 3x3 tag taps (slack included) -- shared by every person
-__global__ __launch_bounds__(256) void tag_bounds_kernel(const DecodeSrc src, float *__restrict__ tagb)
+// The launch also clears the work lists of the arg-max pass (ws_best: n_best entries, ws_jobs: the 8 queue counters), one entry
+// per thread of the grid: two fill launches less in front of refine_mean_kernel.
+__global__ __launch_bounds__(256) void tag_bounds_kernel(const DecodeSrc src, float *__restrict__ tagb, u64 *__restrict__ ws_best,
+                                                         int n_best, int32_t *__restrict__ ws_jobs)
 {
+    {
+        const size_t id = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        if (id < (size_t)n_best) ws_best[id] = 0ull;
+        if (id < 8) ws_jobs[id] = 0;
+    }
     // thread = one quarter-res column x TBR consecutive rows: the 3-wide row minima / maxima are made once per source row and
     // slide down the column (3.75 loads per cell instead of 9; clamped border rows / columns repeat a tap, which min / max ignore)
     constexpr int TBR = 8;
@@ -1209,12 +1217,16 @@ __global__ __launch_bounds__(64) void refine_apply_kernel(const DecodeSrc src, i
 hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev,
                          unsigned long long *ws_best, int32_t *ws_jobs, const float *cellmax, float *tagb, hipStream_t s)
 {
-    if (src.mode == 0)
-        hipLaunchKernelGGL(tag_bounds_kernel, dim3(((((src.H >> 2) + 7) / 8) * (src.W >> 2) + 255) / 256, src.K, src.B), dim3(256), 0, s, src, tagb);  // 8 = TBR
-    hipError_t e = hipMemsetAsync(ws_best, 0, (size_t)src.B * M * src.K * sizeof(u64), s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws_jobs, 0, 32, s);  // the 8 queue counters
-    if (e != hipSuccess) return e;
+    const int nx = ((((src.H >> 2) + 7) / 8) * (src.W >> 2) + 255) / 256;  // 8 = TBR
+    if (src.mode == 0 && (size_t)nx * 256 >= (size_t)M) {  // (grid threads >= B * M * K entries)
+        hipLaunchKernelGGL(tag_bounds_kernel, dim3(nx, src.K, src.B), dim3(256), 0, s, src, tagb, ws_best, src.B * M * src.K, ws_jobs);
+    } else {
+        if (src.mode == 0) hipLaunchKernelGGL(tag_bounds_kernel, dim3(nx, src.K, src.B), dim3(256), 0, s, src, tagb, ws_best, 0, ws_jobs);
+        hipError_t e = hipMemsetAsync(ws_best, 0, (size_t)src.B * M * src.K * sizeof(u64), s);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(ws_jobs, 0, 32, s);  // the 8 queue counters
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(refine_mean_kernel, dim3(src.B), dim3(64), 0, s, src, M, joints, num_people, ws_prev, ws_jobs);
     hipLaunchKernelGGL(refine_argmax_kernel, dim3(2048), dim3(256), 0, s, src, M, ws_jobs, ws_prev, cellmax, tagb, ws_best);
     hipLaunchKernelGGL(refine_apply_kernel, dim3(M, src.B), dim3(64), 0, s, src, M, joints, num_people, ws_best);
