@@ -743,6 +743,9 @@ int hh_net::reserve(int B, int H, int W)
     for (auto &t : tensors) {
         const size_t bytes = (size_t)nB * (nH >> t.shift) * (nW >> t.shift) * t.C * elem();
         if (alloc(bytes, (void **)&t.ptr)) return 1;
+        // HH_POISON_WS=1 (tests): recycled device memory is not zero -- fill the workspace with NaN patterns so that a kernel
+        // that reads what no kernel wrote shows up in the outputs instead of depending on what the allocator hands out
+        if (getenv("HH_POISON_WS")) HH_CHECK_HIP(hipMemset(t.ptr, 0xFF, bytes));
         if (t.zero_init) HH_CHECK_HIP(hipMemset(t.ptr, 0, bytes));
     }
     if (taps_enabled)

@@ -195,6 +195,24 @@ def test_schedule_and_fusion_switches(pkg, net_golden):
                 assert (a - b).abs().max().item() <= 4e-2 * b.abs().max().item() and (a - b).pow(2).mean().sqrt().item() <= 2e-2 * b.pow(2).mean().sqrt().item()
 
 
+def test_forward_reads_no_unwritten_workspace(pkg):
+    """Recycled device memory is not zero: with the workspace filled with NaN patterns at allocation (HH_POISON_WS=1) the forward
+    must give the bits it gives on fresh memory, for growing and shrinking shapes on one handle."""
+    shapes = [(1, 96, 160), (2, 128, 128), (1, 64, 64)]
+    xs = [torch.from_numpy(pkg.synth.synth_images(b, h, w, 30 + i)).to(DEV) for i, (b, h, w) in enumerate(shapes)]
+    clean, _ = _net(pkg, 32, 0)
+    ref = [[t.clone() for t in clean.forward_raw(x)] for x in xs]
+    os.environ["HH_POISON_WS"] = "1"
+    try:
+        for order in ((0, 1, 2), (1, 0, 2, 1)):
+            net, _ = _net(pkg, 32, 0)
+            for i in order:
+                got = net.forward_raw(xs[i])
+                assert all(torch.equal(a, b) for a, b in zip(got, ref[i])), (order, i)
+    finally:
+        del os.environ["HH_POISON_WS"]
+
+
 def test_forward_full_size_samples_and_batch_consistency(pkg, net_golden):
     net, _ = _net(pkg, 32, 0)
     x1 = torch.from_numpy(pkg.synth.synth_images(1, 512, 512, 7)).to(DEV)
