@@ -213,6 +213,25 @@ def train_bench(args, pkg, dist, rank, world, dev):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run the N-rank job as a child `torch.distributed.run` (rendezvous on
+    127.0.0.1, a free port) with this command line, and exit with its code.  Nothing here touches the GPU (counting devices
+    does not initialise it), so the ranks are the first GPU users."""
+    import socket
+    import subprocess
+
+    if os.environ.get("HH_BENCH_REHEARSAL") != "cpu":
+        have = torch.cuda.device_count()
+        if have < n and not os.environ.get("HH_BENCH_REHEARSAL"):
+            sys.exit(f"bench.py: --gpus {n} but this node shows {have} GPU(s)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,9 +262,16 @@ def main():
     cfgd = CONFIGS[args.config]
     if args.batch is None:
         args.batch = cfgd["batch"]
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves -- before this process has made any GPU call -- exactly as
+        # the driver would (one process per GPU under torch.distributed.run), and leave with the launcher's exit code
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:  # never print a line whose n_gpus is not what the command line asked for
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                 f"or run plain `python bench.py --gpus {args.gpus}` and let it start the ranks")
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -20,6 +20,7 @@ hh_net *hh_create(int num_kpts, int C, int dtype)
     if (num_kpts <= 0 || num_kpts > 64 || C <= 0 || C % 16) { hh_set_error("hh_create: need 0 < num_kpts <= 64 and C % 16 == 0"); return nullptr; }
     hh_net *n = new hh_net();
     n->K = num_kpts; n->C = C; n->dtype = dtype;
+    n->sw = PlanSwitches::from_env();
     n->build();
     return n;
 }
@@ -29,6 +30,7 @@ hh_net *hh_create_classifier(int C, int num_classes, int dtype)
     if (C <= 0 || C % 16 || num_classes <= 0) { hh_set_error("hh_create_classifier: need C % 16 == 0 and num_classes > 0"); return nullptr; }
     hh_net *n = new hh_net();
     n->K = 17; n->C = C; n->dtype = dtype; n->kind = 1; n->num_classes = num_classes;
+    n->sw = PlanSwitches::from_env();
     n->build();
     return n;
 }
@@ -488,23 +490,14 @@ int hh_transform_coords(const float *xy_in, int n, double cx, double cy, double 
 
 // ---------------------------------------------------------------------------------------------------
 // Kernel micro-benchmark (tools/conv_bench.py): one convolution shape, random bf16 data, `iters` back-to-back
-// launches of instantiation `cfg` (>= HH_CFG_DMA_BASE: LDS-DMA variant) timed with HIP events.  If `max_diff`
+// launches of instantiation `cfg` timed with HIP events.  If `max_diff`
 // is given, the output is also compared with generic instantiation `ref_cfg` on the same data.  Not on the hot path.
 extern "C" int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, int cout, int with_res, int relu, int iters,
                                    float *ms_per_launch, unsigned long long *stamps16, int ref_cfg, float *max_diff)
 {
     HH_CHECK_HIP(conv_init());
-#ifdef HH_EXPERIMENTAL
-    HH_CHECK_HIP(conv_dma_init());
-#else
-    if (cfg >= HH_CFG_DMA_BASE || ref_cfg >= HH_CFG_DMA_BASE) { hh_set_error("LDS-DMA variants need a `make EXPERIMENTAL=1` build"); return 1; }
-#endif
-    const bool is_dma = cfg >= HH_CFG_DMA_BASE;
-    if (!is_dma && (cfg < 0 || cfg >= conv_num_configs())) { hh_set_error("bad cfg"); return 1; }
-#ifdef HH_EXPERIMENTAL
-    if (is_dma && cfg - HH_CFG_DMA_BASE >= conv_dma_num_variants()) { hh_set_error("bad dma variant"); return 1; }
-#endif
-    ConvConfig c = is_dma ? ConvConfig{3, 1, 16, 2, 1, 1, 32} : conv_config(cfg);
+    if (cfg < 0 || cfg >= conv_num_configs()) { hh_set_error("bad cfg"); return 1; }
+    ConvConfig c = conv_config(cfg);
     if (cin % c.KC) { hh_set_error("cin must be a multiple of the config's KC"); return 1; }
     const int coutp = (cout + c.cout_t() - 1) / c.cout_t() * c.cout_t();
     const int Ho = c.S == 2 ? Hin / 2 : Hin, Wo = c.S == 2 ? Win / 2 : Win;
@@ -537,8 +530,7 @@ extern "C" int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, in
     hipStream_t st;
     HH_CHECK_HIP(hipStreamCreate(&st));
     auto run = [&](int k, bf16_raw *out, int n, float *ms_out) -> int {
-        const bool dma = k >= HH_CFG_DMA_BASE;
-        const ConvConfig cc = dma ? ConvConfig{3, 1, 16, 2, 1, 1, 32} : conv_config(k);
+        const ConvConfig cc = conv_config(k);
         std::vector<bf16_raw> packed;
         hh_pack_weights(W.data(), scale.data(), cc.KS, cin, cout, cc.KC, cc.cout_t(), false, 0, 0, packed);
         bf16_raw *d_w;
@@ -549,13 +541,9 @@ extern "C" int hh_debug_conv_bench(int cfg, int B, int Hin, int Win, int cin, in
         p.res = with_res ? d_res : nullptr; p.res_cs = coutp;
         p.out = out; p.out_cs = coutp; p.Hob = Ho; p.Wob = Wo; p.osy = p.osx = 1;
         p.Ho = Ho; p.Wo = Wo; p.cin = cin; p.cout_real = cout; p.cout_store = coutp; p.relu = relu;
-        p.pad_y = p.pad_x = (cc.KS - 1) / 2; p.B = B; p.zero = d_zero; p.stamps = d_st;
+        p.pad_y = p.pad_x = (cc.KS - 1) / 2; p.B = B; p.stamps = d_st;
         p.tiles_x = (Wo + cc.TW - 1) / cc.TW; p.tiles_y = (Ho + cc.th() - 1) / cc.th(); p.ncg = coutp / cc.cout_t();
-#ifdef HH_EXPERIMENTAL
-        auto launch = [&]() { return dma ? conv_dma_launch(k - HH_CFG_DMA_BASE, p, st) : conv_launch(k, p, st); };
-#else
         auto launch = [&]() { return conv_launch(k, p, st); };
-#endif
         hipEvent_t e0, e1;
         HH_CHECK_HIP(hipEventCreate(&e0));
         HH_CHECK_HIP(hipEventCreate(&e1));

@@ -16,6 +16,24 @@ LaunchProbe &hh_launch_probe()
 void hh_set_error(const std::string &msg) { g_err = msg; }
 const char *hh_get_error() { return g_err.c_str(); }
 
+PlanSwitches PlanSwitches::from_env()
+{
+    auto on = [](const char *name) { const char *v = getenv(name); return v && *v && strcmp(v, "0"); };
+    auto is = [](const char *name, const char *val) { const char *v = getenv(name); return v && !strcmp(v, val); };
+    PlanSwitches s;
+    s.bb32_tile = is("HH_BB32", "tile");
+    s.no_bb64 = on("HH_NO_BB64");
+    s.bb128 = is("HH_BB128", "all") ? 2 : is("HH_BB128", "stage2") ? 1 : 0;
+    s.no_bb_fp8 = on("HH_NO_BB_FP8");
+    s.no_stem_fused = on("HH_NO_STEM_FUSED");
+    s.no_junc_pair = on("HH_NO_JUNC_PAIR");
+    s.full_join = on("HH_FULL_JOIN");
+    s.no_fusion_merge = on("HH_NO_FUSION_MERGE");
+    s.poison_ws = on("HH_POISON_WS");
+    s.poison_lds = on("HH_POISON_LDS");
+    return s;
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static inline bf16_raw f2bf(float f)
@@ -220,14 +238,11 @@ struct Builder {
         // alternations: 5512 / 5511 img/s without it, 5451 / 5432 with it in stage 2 only, 5395 / 5415 everywhere.  Its 150 KB
         // workgroups take whole CUs, while the layer-by-layer launches (64 KB workgroups) share CUs with each other and with
         // the 256-channel branch.  HH_BB128=all | stage2 enables it (serial execution, experiments).
-        // (switches are read when the plan is built, i.e. in hh_create)
-        n.bb32_pc = !(getenv("HH_BB32") && !strcmp(getenv("HH_BB32"), "tile"));  // default: producer / consumer form; HH_BB32=tile: basicblock_fused.hip
-        const char *e128 = getenv("HH_BB128");
-        const bool bb128 = C == 128 && e128 && (!strcmp(e128, "all") || (!strcmp(e128, "stage2") && nscales == 3));
+        const bool bb128 = C == 128 && (n.sw.bb128 == 2 || (n.sw.bb128 == 1 && nscales == 3));
         for (int u = 0; u < 4; ++u) {
             const std::string up = prefix + "." + std::to_string(u);
-            const bool fused_fp8 = n.dtype == 2 && bb_fp8_supported(C) && branch == 0 && !getenv("HH_NO_BB_FP8");  // highest-resolution branch / deconv head
-            if (((C == 32 || (C == 64 && !getenv("HH_NO_BB64")) || bb128) && n.dtype != 2) || fused_fp8) {  // fused kernels, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
+            const bool fused_fp8 = n.dtype == 2 && bb_fp8_supported(C) && branch == 0 && !n.sw.no_bb_fp8;  // highest-resolution branch / deconv head
+            if (((C == 32 || (C == 64 && !n.sw.no_bb64) || bb128) && n.dtype != 2) || fused_fp8) {  // fused kernels, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
                 Op o;
                 o.kind = OP_BB;
                 o.layer = L(up + ".conv1", up + ".bn1", C, C, 3, 1);
@@ -261,17 +276,7 @@ struct Builder {
         // stem (hrnet.py:354-358,378-384)
         // bf16: both stem convolutions in ONE kernel (stem_fused.hip), the half-resolution intermediate never leaves the CU
         // (HH_NO_STEM_FUSED=1 and the fp8 path: two launches through the tensor S1)
-        const bool stem_fused = n.dtype != 2 && !getenv("HH_NO_STEM_FUSED");
-        // Stem and stage 0 are one chain of launches on one resolution.  HH_STAGE0_PARTS=2|4 runs them as part batches on as many
-        // lanes (images are independent), one part's HBM-bound junction kernel beside another's 3x3 conv.  OFF by default: in the
-        // trace the phase shrinks from 1035 to 894 us, but the junctions of the parts mostly run in step (they are 70 % of a
-        // chain) and over the whole forward nothing is left of it (4.63 / 4.68 ms with, 4.62 / 4.67 without; four parts the same).
-        n.split_parts = getenv("HH_STAGE0_PARTS") ? atoi(getenv("HH_STAGE0_PARTS")) : 1;
-        if (n.split_parts != 4 && n.split_parts != 2) n.split_parts = 1;
-        if (n.dtype == 2) n.split_parts = 1;
-        const bool split0 = n.split_parts > 1;
-        if (split0) join(n.split_parts);
-        const size_t split_first = n.ops.size();
+        const bool stem_fused = n.dtype != 2 && !n.sw.no_stem_fused;
         const int S1 = stem_fused ? -1 : T(64, 1), X = T(64, 2);
         {   // conv1 reads the fp32 NCHW images itself (stem_conv.hip): no layout pass, no padded input channels
             Op o;
@@ -289,7 +294,7 @@ struct Builder {
         // bf16: the junctions work in pairs -- units 0 and 2 do not store their 256-channel y, units 1 and 3 make it again per pixel
         // from the previous unit's t2 (two more 1x1 GEMMs) -- so conv2 alternates between two t2 tensors
         // (HH_NO_JUNC_PAIR=1: every junction stores y and the next one reads it)
-        const bool jpair = n.dtype != 2 && !getenv("HH_NO_JUNC_PAIR");
+        const bool jpair = n.dtype != 2 && !n.sw.no_junc_pair;
         const int t1 = T(64, 2), t2 = T(64, 2), t2b = jpair ? T(64, 2) : t2, Y = T(256, 2);
         // conv3 (+ downsample) of unit u and conv1 of unit u+1 are both 1x1: one junction kernel makes y and the next t1 in a
         // single pass over the 256-channel tensor (bottleneck_junction.hip)
@@ -323,16 +328,6 @@ struct Builder {
             prev_conv3 = o.layer;
             n.ops.push_back(o);
         }
-        if (split0) {  // the chain above becomes half 0 on lane 0, a copy of it half 1 on lane 1
-            const size_t split_last = n.ops.size();
-            for (size_t i = split_first; i < split_last; ++i) { n.ops[i].half = 0; n.ops[i].lane = 0; }
-            for (int part = 1; part < n.split_parts; ++part)
-                for (size_t i = split_first; i < split_last; ++i) {
-                    Op o = n.ops[i];
-                    o.half = part; o.lane = part;
-                    n.ops.push_back(o);
-                }
-        }
         tap("stem#0", X, 64);
         tap("stages.0.blocks.0#0", Y, 256);
         tap("stages.0.blocks.1#0", Y, 256);  // single-scale fusion = ReLU of a ReLU output
@@ -341,7 +336,7 @@ struct Builder {
         x[0] = T(w[0], 2); x[1] = T(w[1], 3);
         {
             const std::string tp = bb + ".stages.0.transition_layer.transition_blocks";
-            join(n.split_parts > 2 ? n.split_parts : 2);
+            join(2);
             lane = 0; cb(tp + ".0", "0", "1", 256, w[0], 3, 1, Y, x[0], 1);
             lane = 1; cb(tp + ".1", "0", "1", 256, w[1], 3, 2, Y, x[1], 1);
             lane = 0;
@@ -369,7 +364,7 @@ struct Builder {
                 // every fusion output reads every branch -- but not all of them at once: the lanes note their positions and
                 // every output waits, source by source, right in front of the first launch that needs the source
                 // (HH_FULL_JOIN=1: an all-to-all join here instead)
-                const bool fine = !getenv("HH_FULL_JOIN");
+                const bool fine = !n.sw.full_join;
                 if (fine) mark(nsc); else join(nsc);
                 for (int i = 0; i < nsc; ++i)
                     tap("stages." + std::to_string(s) + ".blocks." + std::to_string(2 * b) + "#" + std::to_string(i), x[i], w[i]);
@@ -401,7 +396,7 @@ struct Builder {
                     // output's, so the sum of those convs is one conv over the concatenated channels -- one launch instead of i
                     // dependent ones on the lane that already has the longest chain.  Its inputs must share a pixel stride: chain
                     // intermediates are allocated with the stride of branch i-1.  (HH_NO_FUSION_MERGE=1: one launch per source)
-                    if (i >= 2 && n.dtype != 2 && !getenv("HH_NO_FUSION_MERGE")) {
+                    if (i >= 2 && n.dtype != 2 && !n.sw.no_fusion_merge) {
                         int srcs[3] = {-1, -1, -1};
                         ConvLayer ml;
                         ml.cout = w[i]; ml.ks = 3; ml.stride = 2; ml.cin = 0;
@@ -459,7 +454,7 @@ struct Builder {
                 const std::string q = sp + ".transition_layer.transition_blocks." + std::to_string(nsc);
                 x[nsc] = T(w[nsc], 2 + nsc);
                 // the new lane needs branch nsc-1's fusion output only, the others go straight on to the next stage's blocks
-                if (!getenv("HH_FULL_JOIN")) { mark(nsc + 1); waitl(nsc, nsc - 1); }
+                if (!n.sw.full_join) { mark(nsc + 1); waitl(nsc, nsc - 1); }
                 else join(nsc + 1);
                 lane = nsc;  // the new branch starts on its own lane
                 cb(q, "0", "1", w[nsc - 1], w[nsc], 3, 2, x[nsc - 1], x[nsc], 1);
@@ -471,7 +466,7 @@ struct Builder {
             } else {
                 // HigherHRNet: only lane 0 goes on (it has waited for the others source by source); the forward's closing edges
                 // collect the rest.  The classification head reads all four branches on lane 0.
-                if (n.kind != 0 || getenv("HH_FULL_JOIN")) join(4);
+                if (n.kind != 0 || n.sw.full_join) join(4);
                 if (n.kind == 0) tap("stages.3#0", CAT, w[0]);
             }
         }
@@ -589,10 +584,6 @@ int hh_net::finalize()
     HH_CHECK_HIP(bbpc_init());
     HH_CHECK_HIP(bb64_fused_init());
     HH_CHECK_HIP(bb128_fused_init());
-#ifdef HH_EXPERIMENTAL
-    HH_CHECK_HIP(bb_thin_init());
-    bb32_thin = getenv("HH_BB32") && !strcmp(getenv("HH_BB32"), "thin");
-#endif
     HH_CHECK_HIP(junction_init());
     if (dtype == 2 && kind != 0) { hh_set_error("hh_finalize: the fp8 path covers HigherHRNet only"); return 1; }
     {
@@ -745,7 +736,7 @@ int hh_net::reserve(int B, int H, int W)
         if (alloc(bytes, (void **)&t.ptr)) return 1;
         // HH_POISON_WS=1 (tests): recycled device memory is not zero -- fill the workspace with NaN patterns so that a kernel
         // that reads what no kernel wrote shows up in the outputs instead of depending on what the allocator hands out
-        if (getenv("HH_POISON_WS")) HH_CHECK_HIP(hipMemset(t.ptr, 0xFF, bytes));
+        if (sw.poison_ws) HH_CHECK_HIP(hipMemset(t.ptr, 0xFF, bytes));
         if (t.zero_init) HH_CHECK_HIP(hipMemset(t.ptr, 0, bytes));
     }
     if (taps_enabled)
@@ -788,7 +779,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
     // Lanes: the resolution branches of an HR block and the outputs of a fusion layer are independent, so they run
     // on separate HIP streams (forked from / joined to the caller's stream with events; the same calls become
     // DAG edges under hipGraph capture).  The small low-resolution launches then fill CUs the big ones leave idle.
-    const bool multi = multi_lane && !taps_enabled && !prof_enabled && !calibrating;
+    const bool multi = multi_lane && !taps_enabled && !prof_enabled && !calibrating && !sw.poison_lds;
     if (multi) {
         // The lanes take the PRIORITY of the caller's stream.  A caller on a highest-priority stream gets its whole forward
         // on high-priority queues (dependent launches follow each other faster there: forward 5.25 -> 4.98 ms at batch 32),
@@ -805,16 +796,11 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         }
     }
     hipStream_t L[4] = {s0, multi ? lane_streams[1] : s0, multi ? lane_streams[2] : s0, multi ? lane_streams[3] : s0};
-    if (multi && getenv("HH_LANE_MAP")) {  // experiment: several lanes on one stream, e.g. 0012 = branches 0 and 1 share the caller's stream
-        const char *m = getenv("HH_LANE_MAP");
-        hipStream_t all[4] = {s0, lane_streams[1], lane_streams[2], lane_streams[3]};
-        for (int l = 0; l < 4 && m[l]; ++l) L[l] = all[(m[l] - '0') & 3];
-    }
     lane_events_used = 0;
     auto next_event = [&](hipEvent_t *e) -> int {
         if (lane_events_used == lane_events.size()) {
             hipEvent_t ne;
-            HH_CHECK_HIP(hipEventCreateWithFlags(&ne, getenv("HH_EVENT_DEFAULT") ? hipEventDefault : hipEventDisableTiming));
+            HH_CHECK_HIP(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
             lane_events.push_back(ne);
         }
         *e = lane_events[lane_events_used++];
@@ -834,20 +820,10 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
     }
     int lanes_open = 1;  // lanes [0, lanes_open) have work that the caller's stream must wait for at the end
     hipEvent_t mark_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    const int Bfull = B;
     for (const Op &op : ops) {
         hipStream_t s = L[op.lane];
-        // half-batch ops: B / boff replace the batch size and select the images (every tensor is batch-major)
-        int boff = 0;
-        B = Bfull;
-        if (op.half >= 0 && Bfull < 4 * split_parts) {  // small batches: the extra launches cost more than the overlap gives; part 0 takes all
-            if (op.half > 0) continue;
-        } else if (op.half >= 0) {
-            const int B0 = (Bfull + split_parts - 1) / split_parts;
-            boff = op.half * B0;
-            B = Bfull - boff < B0 ? Bfull - boff : B0;
-            if (B <= 0) continue;
-        }
+        if (sw.poison_lds && op.kind != OP_JOIN && op.kind != OP_MARK && op.kind != OP_WAITL && op.kind != OP_DEP && op.kind != OP_TAP)
+            HH_CHECK_HIP(launch_lds_poison(num_cus, s));
         switch (op.kind) {
         case OP_JOIN: {
             if (!multi) break;
@@ -868,6 +844,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         case OP_MARK: {
             if (!multi) break;
             const int nrec = op.nlanes < lanes_open ? op.nlanes : lanes_open;
+            for (int l = 0; l < 4; ++l) mark_ev[l] = nullptr;  // a wait may only name a lane THIS mark recorded
             for (int l = 0; l < nrec; ++l) {
                 if (next_event(&mark_ev[l])) return 1;
                 HH_CHECK_HIP(hipEventRecord(mark_ev[l], L[l]));
@@ -877,6 +854,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         }
         case OP_WAITL: {
             if (!multi) break;
+            if (!mark_ev[op.dep_from]) { hh_set_error("plan: OP_WAITL names a lane the last OP_MARK did not record"); return 1; }
             HH_CHECK_HIP(hipStreamWaitEvent(L[op.lane], mark_ev[op.dep_from], 0));
             break;
         }
@@ -893,8 +871,8 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             if (op.layer2 >= 0) {  // both stem convolutions in one kernel
                 const ConvLayer &l2 = layers[op.layer2];
                 StemFusedParams q{};
-                q.images = images + (size_t)boff * 3 * H * W; q.w1 = l.d_w; q.b1 = l.d_bias; q.w2 = l2.d_w; q.b2 = l2.d_bias;
-                q.out = tensors[op.out].ptr + (size_t)boff * (H / 4) * (W / 4) * tensors[op.out].C; q.out_cs = tensors[op.out].C;
+                q.images = images; q.w1 = l.d_w; q.b1 = l.d_bias; q.w2 = l2.d_w; q.b2 = l2.d_bias;
+                q.out = tensors[op.out].ptr; q.out_cs = tensors[op.out].C;
                 q.B = B; q.H = H; q.W = W;
                 if (!stem_fused_supported(q)) { hh_set_error("hh_forward: the fused stem needs H, W multiples of 4 and images below 2 GB (HH_NO_STEM_FUSED=1)"); return 1; }
                 if (prof_enabled) {
@@ -917,8 +895,8 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 break;
             }
             StemParams p{};
-            p.images = images + (size_t)boff * 3 * H * W; p.w = l.d_w; p.bias = l.d_bias;
-            p.out = tensors[op.out].ptr + (size_t)boff * (H / 2) * (W / 2) * tensors[op.out].C; p.out_cs = tensors[op.out].C;
+            p.images = images; p.w = l.d_w; p.bias = l.d_bias;
+            p.out = tensors[op.out].ptr; p.out_cs = tensors[op.out].C;
             p.B = B; p.H = H; p.W = W;
             if (dtype == 2) {
                 p.out_fp8 = (unsigned char *)tensors[op.out].ptr; p.out_inv_scale = 1.f / op.s_out;
@@ -986,17 +964,16 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             const ConvLayer &l3 = layers[op.layer];
             JuncParams p{};
             const TensorDesc &ti = tensors[op.in];
-            const size_t pix0 = (size_t)boff * (H >> ti.shift) * (W >> ti.shift);  // first pixel of this op's images
-            p.t2 = tensors[op.in].ptr + pix0 * tensors[op.in].C; p.t2_cs = tensors[op.in].C;
-            if (op.res >= 0) { p.res = tensors[op.res].ptr + pix0 * tensors[op.res].C; p.res_cs = tensors[op.res].C; }
-            if (op.in2 >= 0) { p.x = tensors[op.in2].ptr + pix0 * tensors[op.in2].C; p.x_cs = tensors[op.in2].C; p.wd = layers[op.layer2].d_w; p.bd = layers[op.layer2].d_bias; }
+            p.t2 = tensors[op.in].ptr; p.t2_cs = tensors[op.in].C;
+            if (op.res >= 0) { p.res = tensors[op.res].ptr; p.res_cs = tensors[op.res].C; }
+            if (op.in2 >= 0) { p.x = tensors[op.in2].ptr; p.x_cs = tensors[op.in2].C; p.wd = layers[op.layer2].d_w; p.bd = layers[op.layer2].d_bias; }
             p.w3 = l3.d_w; p.b3 = l3.d_bias;
             if (op.layer4 >= 0) {
-                p.t2a = tensors[op.in3].ptr + pix0 * tensors[op.in3].C; p.t2a_cs = tensors[op.in3].C;
+                p.t2a = tensors[op.in3].ptr; p.t2a_cs = tensors[op.in3].C;
                 p.w3a = layers[op.layer4].d_w; p.b3a = layers[op.layer4].d_bias;
             }
-            if (op.layer3 >= 0) { p.w1 = layers[op.layer3].d_w; p.b1 = layers[op.layer3].d_bias; p.t1 = tensors[op.out2].ptr + pix0 * tensors[op.out2].C; p.t1_cs = tensors[op.out2].C; }
-            if (op.out >= 0) { p.y = tensors[op.out].ptr + pix0 * tensors[op.out].C; p.y_cs = tensors[op.out].C; }
+            if (op.layer3 >= 0) { p.w1 = layers[op.layer3].d_w; p.b1 = layers[op.layer3].d_bias; p.t1 = tensors[op.out2].ptr; p.t1_cs = tensors[op.out2].C; }
+            if (op.out >= 0) { p.y = tensors[op.out].ptr; p.y_cs = tensors[op.out].C; }
             p.npix = B * (H >> ti.shift) * (W >> ti.shift);
             ProfRecord *pr = nullptr;
             if (prof_enabled) {
@@ -1064,10 +1041,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             }
             if (l1.cout == 128) HH_CHECK_HIP(bb128_fused_launch(p, num_cus, s));
             else if (l1.cout == 64) HH_CHECK_HIP(bb64_fused_launch(p, num_cus, s));
-#ifdef HH_EXPERIMENTAL
-            else if (bb32_thin) HH_CHECK_HIP(bb_thin_launch(p, num_cus, s));
-#endif
-            else if (bb32_pc && bbpc_supported(p)) HH_CHECK_HIP(bbpc_launch(p, num_cus, s));
+            else if (!sw.bb32_tile && bbpc_supported(p)) HH_CHECK_HIP(bbpc_launch(p, num_cus, s));
             else HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
             break;
         }
@@ -1092,7 +1066,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             const TensorDesc &ti = tensors[op.in];
             ConvParams p{};
             p.Hin = H >> ti.shift; p.Win = W >> ti.shift;
-            p.in = ti.ptr + (size_t)boff * p.Hin * p.Win * ti.C; p.in_cs = ti.C; p.in_coff = op.in_coff;
+            p.in = ti.ptr; p.in_cs = ti.C; p.in_coff = op.in_coff;
             p.w = l.d_w; p.bias = l.d_bias;
             p.Ho = l.stride == 2 ? p.Hin / 2 : p.Hin;
             p.Wo = l.stride == 2 ? p.Win / 2 : p.Win;
@@ -1106,11 +1080,11 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             p.Hob = p.Ho * p.osy; p.Wob = p.Wo * p.osx;
             if (op.out >= 0) {
                 const TensorDesc &to = tensors[op.out];
-                p.out = to.ptr + (size_t)boff * p.Hob * p.Wob * to.C; p.out_cs = to.C; p.out_coff = op.out_coff;
+                p.out = to.ptr; p.out_cs = to.C; p.out_coff = op.out_coff;
             }
             if (op.res >= 0) {
                 const TensorDesc &tr = tensors[op.res];
-                p.res = tr.ptr + (size_t)boff * p.Hob * p.Wob * tr.C; p.res_cs = tr.C; p.res_coff = op.res_coff;
+                p.res = tr.ptr; p.res_cs = tr.C; p.res_coff = op.res_coff;
             }
             p.out_f32 = op.f32_out == 1 ? o1 : op.f32_out == 2 ? o2 : nullptr;
             if (op.in2 >= 0) {  // conv over the concatenated channels of two or three tensors of one shape and pixel stride
@@ -1160,7 +1134,6 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         }
         }
     }
-    B = Bfull;
     if (multi)
         for (int l = 1; l < lanes_open; ++l) {  // close the fork: the caller's stream waits for every lane
             hipEvent_t e;
@@ -1188,7 +1161,7 @@ int hh_net::forward(const float *images, int B, int H, int W, float *o1, float *
             return 0;
         }
     hipGraph_t graph;
-    HH_CHECK_HIP(hipStreamBeginCapture(s, getenv("HH_CAPTURE_MODE") ? (hipStreamCaptureMode)atoi(getenv("HH_CAPTURE_MODE")) : hipStreamCaptureModeThreadLocal));
+    HH_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = enqueue(images, B, H, W, o1, o2, s);
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc) return rc;
@@ -1214,10 +1187,10 @@ int hh_net::check_plan(std::string *why) const
     struct Stamp { int lane; int t; int op; };
     int clk[4][4] = {};  // clk[l][m] = latest event of lane m that lane l is ordered after
     int mark_clk[4][4] = {};  // the lanes' clocks at the last OP_MARK
+    bool mark_ok[4] = {false, false, false, false};  // lanes the last OP_MARK recorded
     auto before = [&](const Stamp &st, int lane) { return st.lane < 0 || clk[lane][st.lane] >= st.t; };
-    // (every tensor counts as four resources, quarters of the batch: an op on part `half` of the batch touches that part's)
-    std::vector<Stamp> writer(4 * tensors.size(), Stamp{-1, 0, -1});
-    std::vector<std::vector<Stamp>> readers(4 * tensors.size());
+    std::vector<Stamp> writer(tensors.size(), Stamp{-1, 0, -1});
+    std::vector<std::vector<Stamp>> readers(tensors.size());
     int lanes_open = 1;
     for (size_t i = 0; i < ops.size(); ++i) {
         const Op &op = ops[i];
@@ -1237,12 +1210,14 @@ int hh_net::check_plan(std::string *why) const
         }
         if (op.kind == OP_MARK) {
             const int nrec = op.nlanes < lanes_open ? op.nlanes : lanes_open;
+            for (int m = 0; m < 4; ++m) mark_ok[m] = m < nrec;
             for (int m = 0; m < nrec; ++m)
                 for (int c = 0; c < 4; ++c) mark_clk[m][c] = clk[m][c];
             if (op.nlanes > lanes_open) lanes_open = op.nlanes;
             continue;
         }
         if (op.kind == OP_WAITL) {
+            if (!mark_ok[op.dep_from]) { if (why) *why = "op " + std::to_string(i) + " waits for a lane the last mark did not record"; return 1; }
             for (int c = 0; c < 4; ++c) clk[op.lane][c] = std::max(clk[op.lane][c], mark_clk[op.dep_from][c]);
             continue;
         }
@@ -1259,21 +1234,11 @@ int hh_net::check_plan(std::string *why) const
         case OP_AVGPOOL: rd = {op.in}; break;
         default: break;
         }
-        {   // tensor ids -> (tensor, half) resources
-            std::vector<int> rd2, wr2;
-            const int per = 4 / (split_parts > 1 ? split_parts : 1);  // sub-resources of one part
-            for (int q = 0; q < 4; ++q) {
-                if (op.half >= 0 && q / per != op.half) continue;
-                for (int x : rd) if (x >= 0) rd2.push_back(4 * x + q);
-                for (int x : wr) if (x >= 0) wr2.push_back(4 * x + q);
-            }
-            rd.swap(rd2); wr.swap(wr2);
-        }
         const int t = ++clk[l][l];
         for (int x : rd) {
             if (x < 0) continue;
             if (!before(writer[x], l)) {
-                if (why) *why = "RAW: op " + std::to_string(i) + " (lane " + std::to_string(l) + ") reads tensor " + std::to_string(x >> 2) +
+                if (why) *why = "RAW: op " + std::to_string(i) + " (lane " + std::to_string(l) + ") reads tensor " + std::to_string(x) +
                                 " written by op " + std::to_string(writer[x].op) + " (lane " + std::to_string(writer[x].lane) + ") without an edge";
                 return 1;
             }
@@ -1281,12 +1246,12 @@ int hh_net::check_plan(std::string *why) const
         for (int x : wr) {
             if (x < 0) continue;
             if (!before(writer[x], l)) {
-                if (why) *why = "WAW: op " + std::to_string(i) + " overwrites tensor " + std::to_string(x >> 2) + " of op " + std::to_string(writer[x].op);
+                if (why) *why = "WAW: op " + std::to_string(i) + " overwrites tensor " + std::to_string(x) + " of op " + std::to_string(writer[x].op);
                 return 1;
             }
             for (const Stamp &r : readers[x])
                 if (!(r.lane == l) && !before(r, l)) {
-                    if (why) *why = "WAR: op " + std::to_string(i) + " (lane " + std::to_string(l) + ") overwrites tensor " + std::to_string(x >> 2) +
+                    if (why) *why = "WAR: op " + std::to_string(i) + " (lane " + std::to_string(l) + ") overwrites tensor " + std::to_string(x) +
                                     " still read by op " + std::to_string(r.op) + " (lane " + std::to_string(r.lane) + ")";
                     return 1;
                 }

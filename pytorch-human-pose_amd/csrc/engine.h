@@ -77,8 +77,6 @@ struct Op {
     int up[3] = {-1, -1, -1}, up_shift[3] = {0, 0, 0}, nup = 0;
     int C = 0;  // UPADD channel count / TAP channel count
     int tap = -1;
-    int half = -1;    // >= 0: the op works on part `half` of the batch only (hh_net::split_parts equal parts: stem + stage 0 run as
-                      // part batches on as many lanes: one part's HBM-bound junction beside another's 3x3 conv); -1: the whole batch
     int lane = 0;     // execution lane (HIP stream): resolution branches / fusion outputs run concurrently
     int nlanes = 0;   // OP_JOIN: all-to-all barrier over lanes [0, nlanes)
     int dep_from = 0; // OP_DEP: `lane` waits for everything enqueued so far on lane dep_from; OP_WAITL: `lane` waits for lane dep_from's
@@ -108,6 +106,23 @@ struct GraphEntry {
     void *o1, *o2;
     int B, H, W;
     hipGraphExec_t exec;
+};
+
+// Plan variants behind HH_* environment switches (A/B measurements, bit-equality tests).  hh_create / hh_create_classifier read
+// them ONCE (PlanSwitches::from_env) into the handle: nothing in the engine calls getenv afterwards, so a handle's plan and
+// launch choices cannot change under it when a later handle is built with other switches in the same process.
+struct PlanSwitches {
+    bool bb32_tile = false;        // HH_BB32=tile: basicblock_fused.hip instead of the producer / consumer form
+    bool no_bb64 = false;          // HH_NO_BB64=1: 64-channel BasicBlocks layer by layer
+    int bb128 = 0;                 // HH_BB128=all (2) | stage2 (1): fused 128-channel BasicBlock (off by default: loses beside the lanes)
+    bool no_bb_fp8 = false;        // HH_NO_BB_FP8=1: fp8 BasicBlocks layer by layer
+    bool no_stem_fused = false;    // HH_NO_STEM_FUSED=1: the stem as two launches
+    bool no_junc_pair = false;     // HH_NO_JUNC_PAIR=1: every stage-0 junction stores its 256-channel output
+    bool full_join = false;        // HH_FULL_JOIN=1: all-to-all joins of the branch lanes instead of per-source waits
+    bool no_fusion_merge = false;  // HH_NO_FUSION_MERGE=1: one launch per summed stride-2 conv of a fusion layer
+    bool poison_ws = false;        // HH_POISON_WS=1 (tests): workspace filled with NaN patterns at allocation
+    bool poison_lds = false;       // HH_POISON_LDS=1 (tests): every CU's LDS filled with NaN patterns in front of every launch
+    static PlanSwitches from_env();
 };
 
 struct hh_net {
@@ -144,9 +159,7 @@ struct hh_net {
     std::vector<hipEvent_t> lane_events;
     size_t lane_events_used = 0;
     bool multi_lane = true;
-    int split_parts = 1;     // number of part batches stem + stage 0 run as (HH_STAGE0_PARTS = 2 or 4; default 1 = not split)
-    bool bb32_pc = true;     // the producer / consumer form of the fused 32-channel block (HH_BB32=tile selects the tile form)
-    bool bb32_thin = false;  // HH_BB32=thin: the half-CU variant of the fused 32-channel block (experiment switch)
+    PlanSwitches sw;         // plan variants, read from the environment ONCE in hh_create and kept for the life of the handle
     // fp8 path (dtype == HH_DTYPE_FP8)
     bool calibrated = false;      // activation scales set (hh_calibrate)
     bool calibrating = false;     // the running forward records per-op output maxima

@@ -48,7 +48,6 @@ struct ConvParams {
     size_t phase_stride;  //    phase index, weights of phase f start at w + f * phase_stride elements); 0 or 1: plain conv
     unsigned long long *stamps;  // diagnostic build (-DHH_STAMP) only
     unsigned long long *clk;     // optional {min start, max end} of the launch in wall_clock64() ticks (profiling probe)
-    const bf16_raw *zero;        // >= 16 zero bytes (16-B aligned): DMA source of out-of-image pixels (conv3x3_dma.hip)
     // Several input tensors as ONE conv over their concatenated channels (the summed stride-2 convs of a fusion layer,
     // hrnet.py:166-229): same spatial dims and the same pixel stride as `in`; chunks [0, nch0) come from `in`, the next nch1 from
     // in + src_delta1 elements, the rest from in + src_delta2.  nch0 = 0: a single input.
@@ -74,13 +73,6 @@ const ConvConfig &conv_config(int i);
 // Launches config `cfg_index`; the grid is B*tiles_y*tiles_x*ncg blocks of 256 threads.
 hipError_t conv_launch(int cfg_index, const ConvParams &p, hipStream_t stream);
 hipError_t conv_init();  // raises the dynamic-LDS limit of every instantiation
-
-// LDS-DMA 3x3 stride-1 kernel for the 64..256-channel branches (conv3x3_dma.hip); weights packed with KC=16, COUT_T=64.
-#define HH_CFG_DMA_BASE 200
-int conv_dma_num_variants();
-void conv_dma_variant(int v, int *PT, int *TW);
-hipError_t conv_dma_init();
-hipError_t conv_dma_launch(int variant, ConvParams p, hipStream_t s);
 
 // ---- fp8 path (conv_fp8.hip): e4m3 NHWC activations with one scale per tensor, e4m3 weights with one scale per cout
 struct Fp8ConvParams {
@@ -163,11 +155,6 @@ hipError_t bbpc_init();
 bool bbpc_supported(const BBParams &p);
 hipError_t bbpc_launch(BBParams p, int num_cus, hipStream_t s);
 // the same block for the 64-channel branch (basicblock_fused_c64.hip): weights packed KS=3,S=1,KC=32,NT=2 ([chunk][tap][4][64][8])
-// "thin" variant of the 32-channel block (experimental/basicblock_fused_thin.hip, EXPERIMENTAL=1 builds only): half a CU per
-// workgroup, weights in registers; measured SLOWER than basicblock_fused.hip (forward 5.67 vs 5.09 ms with the lanes, 6.54 vs
-// 5.99 ms serial, tools/probes/ab_thin.sh)
-hipError_t bb_thin_init();
-hipError_t bb_thin_launch(BBParams p, int num_cus, hipStream_t s);
 #define HH_CFG_BB128_FUSED 104
 // ... and for the 128-channel branch (basicblock_fused_c128.hip): weights packed KS=3,S=1,KC=16,COUT_T=128 ([chunk][tap][2][128][8])
 hipError_t bb128_fused_init();
@@ -247,6 +234,7 @@ struct UpAddFp8Params {
 hipError_t launch_upadd_fp8(const UpAddFp8Params &p, hipStream_t s);
 
 // ClassificationHead tail: global average pool (bf16 NHWC -> fp32 [B,C]) and Linear (fp32)
+hipError_t launch_lds_poison(int num_cus, hipStream_t s);  // debug: NaN patterns into every CU's LDS (misc_kernels.hip)
 hipError_t launch_avgpool(const bf16_raw *in, int in_cs, float *out, int B, int HW, int C, hipStream_t s);
 hipError_t launch_linear(const float *x, const float *w, const float *bias, float *y, int B, int K, int N, hipStream_t s);
 

@@ -324,3 +324,32 @@ hipError_t launch_preprocess(const unsigned char *img, int h, int w, const doubl
     return hipGetLastError();
 }
 
+
+// HH_POISON_LDS=1 (tests, hh_net::enqueue): LDS is not cleared between kernels -- a workgroup finds what the last workgroup on its CU
+// left there.  This kernel leaves bf16 / fp32 NaN patterns (0xFF bytes) in all 160 KB of every CU's LDS, so that a kernel whose
+// result depends on LDS bytes it never wrote (a halo nobody staged, padding taps multiplied by zero weights) shows NaNs in its
+// output instead of depending on which kernels ran before it.  One workgroup needs a whole CU's LDS, so workgroups only land on
+// CUs whose LDS is free; 8 per CU, each lingering ~2 us, so that the dispatcher reaches every CU.
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned *sink)
+{
+    extern __shared__ uint4 lds_all[];
+    const uint4 nan4 = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    for (int i = threadIdx.x; i < 160 * 1024 / 16; i += 256) lds_all[i] = nan4;
+    __syncthreads();
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
+    if (lds_all[threadIdx.x].x != 0xffffffffu) *sink = 1;  // (keeps the stores alive)
+}
+hipError_t launch_lds_poison(int num_cus, hipStream_t s)
+{
+    static unsigned *sink[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!sink[dev & 63]) {
+        if ((e = hipFuncSetAttribute((const void *)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&sink[dev & 63], 64)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(8 * num_cus), dim3(256), 160 * 1024, s, sink[dev & 63]);
+    return hipGetLastError();
+}

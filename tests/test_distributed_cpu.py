@@ -113,3 +113,29 @@ def test_bench_multi_rank_launch_contract_two_ranks():
     assert r["ms_per_step"] >= 4.0
     # ... and the value is the whole-job aggregate over both ranks for that time
     assert abs(r["value"] - 2 * batch / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-3
+
+
+def test_bench_gpus_flag_without_a_launcher_starts_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no torch.distributed.run around it): bench.py starts the two ranks itself before touching
+    a GPU and prints the N = 2 line; with a WORLD_SIZE that contradicts --gpus it refuses instead of reporting the wrong n_gpus."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HH_BENCH_REHEARSAL="cpu", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["config"]["global_batch"] == 64
+    # a launcher that gives one rank to a command line asking for eight: no line, non-zero exit
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+    assert "--gpus 8 but WORLD_SIZE=1" in bad.stderr
+    # more GPUs than the node has (none here): refused before anything is launched
+    env2 = {k: v for k, v in env.items() if k != "HH_BENCH_REHEARSAL"}
+    none = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                          env=env2, capture_output=True, text=True, timeout=120)
+    assert none.returncode != 0 and "shows" in none.stderr and not [l for l in none.stdout.splitlines() if l.startswith("{")]

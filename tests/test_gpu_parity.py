@@ -36,6 +36,32 @@ def _close(got, ref, what):
     return emax, erms
 
 
+def _same_bits(a, b, what):
+    """Bit equality with a message that says WHERE two tensors differ (round 2 lost the text of a one-off failure)."""
+    if torch.equal(a, b):
+        return
+    d = (a != b) | (a.isnan() != b.isnan())
+    idx = d.nonzero()
+    first = tuple(idx[0].tolist())
+    raise AssertionError(f"{what}: {int(d.sum())} of {d.numel()} values differ, first at {first}: {a[first].item()!r} vs {b[first].item()!r}; "
+                         f"NaNs {int(a.isnan().sum())} / {int(b.isnan().sum())}; differing index range {idx.min(0).values.tolist()} .. {idx.max(0).values.tolist()}")
+
+
+def _switch_env(env):
+    """Context: HH_* plan switches are read once in hh_create -- set them around the construction of a net only."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        os.environ.update(env)
+        try:
+            yield
+        finally:
+            for k in env:
+                del os.environ[k]
+    return cm()
+
+
 def test_native_library_is_the_one_running(pkg):
     assert torch.cuda.is_available()
     lib = pkg._lib.load()
@@ -153,23 +179,6 @@ def test_fused_stem_matches_two_launches(pkg, net_golden):
             assert (u - v).abs().max().item() <= 4e-2 * v.abs().max().item() and (u - v).pow(2).mean().sqrt().item() <= 2e-2 * v.pow(2).mean().sqrt().item(), shape
 
 
-def test_stage0_part_batches_opt_in(pkg):
-    """HH_STAGE0_PARTS=2|4 (off by default): stem + stage 0 as part batches on separate lanes.  Images are
-    independent and every part runs the same kernels, so the outputs equal the unsplit plan's bit for bit -- odd batch included."""
-    x = torch.from_numpy(pkg.synth.synth_images(9, 64, 96, 3)).to(DEV)
-    ref_net, _ = _net(pkg, 32, 2)
-    ref = [t.clone() for t in ref_net.forward_raw(x)]
-    for parts in ("2", "4"):
-        os.environ["HH_STAGE0_PARTS"] = parts
-        try:
-            net, _ = _net(pkg, 32, 2)
-        finally:
-            del os.environ["HH_STAGE0_PARTS"]
-        for _ in range(3):
-            got = net.forward_raw(x)
-            assert all(torch.equal(a, b) for a, b in zip(got, ref)), parts
-
-
 def test_schedule_and_fusion_switches(pkg, net_golden):
     """The plan variants behind the engine switches: all-to-all joins (HH_FULL_JOIN=1) give the default plan's bits (same kernels,
     other edges), and so do stage-0 junctions that each store their y (HH_NO_JUNC_PAIR=1: the pair mode makes the previous
@@ -213,6 +222,70 @@ def test_forward_reads_no_unwritten_workspace(pkg):
         del os.environ["HH_POISON_WS"]
 
 
+def test_forward_does_not_depend_on_stale_lds(pkg):
+    """LDS is not cleared between kernels: with NaN patterns left in every CU's 160 KB in front of every launch
+    (HH_POISON_LDS=1, one lane) the forward must give the bits it gives otherwise -- at 512x512 with B = 1 and B = 4 (the shapes of
+    the one unexplained round-2 failure), on ragged shapes, and for every plan variant."""
+    cases = [(1, 512, 512), (4, 512, 512), (1, 96, 160), (3, 64, 96), (2, 128, 128)]
+    xs = [torch.from_numpy(pkg.synth.synth_images(b, h, w, 40 + i)).to(DEV) for i, (b, h, w) in enumerate(cases)]
+    variants = [{}, {"HH_BB32": "tile"}, {"HH_NO_BB64": "1"}, {"HH_BB128": "all"}, {"HH_NO_STEM_FUSED": "1"}, {"HH_NO_JUNC_PAIR": "1"},
+                {"HH_NO_FUSION_MERGE": "1"}]
+    for env in variants:
+        with _switch_env(env):
+            clean, _ = _net(pkg, 32, 0)
+        with _switch_env(dict(env, HH_POISON_LDS="1")):
+            dirty, _ = _net(pkg, 32, 0)
+        for x, shape in zip(xs if not env else xs[:3], cases):
+            ref = [t.clone() for t in clean.forward_raw(x)]
+            got = dirty.forward_raw(x)
+            for a, b, name in zip(got, ref, ("init_heatmaps", "deconv_heatmaps")):
+                _same_bits(a, b, f"{env} {shape} {name} with poisoned LDS")
+
+
+def test_many_live_handles_interleaved_forwards_stay_bit_exact(pkg):
+    """Cross-handle state (round 2's open item): 16 handles over the plan switches stay ALIVE in one process, and B = 1 / B = 4
+    forwards at 512x512 are interleaved over all of them for 50 rounds.  Every bit-exact variant must keep returning the bits a
+    fresh default handle gave before the others existed; the two variants that round differently (tile-form block, unmerged
+    fusion convs) must each keep returning their own first result."""
+    x1 = torch.from_numpy(pkg.synth.synth_images(1, 512, 512, 7)).to(DEV)
+    xb = torch.from_numpy(pkg.synth.synth_images(4, 512, 512, 8)).to(DEV)
+    xb[0] = x1[0]
+    xb[3] = x1[0]
+    first, _ = _net(pkg, 32, 0)
+    ref1 = [t.clone() for t in first.forward_raw(x1)]
+    ref4 = [t.clone() for t in first.forward_raw(xb)]
+    _same_bits(ref4[0][0], ref1[0][0], "fresh handle: init_heatmaps slot 0 vs batch of 1")
+    _same_bits(ref4[1][3], ref1[1][0], "fresh handle: deconv_heatmaps slot 3 vs batch of 1")
+    exact = [{}, {"HH_FULL_JOIN": "1"}, {"HH_NO_JUNC_PAIR": "1"}, {"HH_FULL_JOIN": "1", "HH_NO_JUNC_PAIR": "1"}, {}, {}]
+    own = [{"HH_NO_STEM_FUSED": "1"}, {"HH_NO_STEM_FUSED": "1", "HH_NO_JUNC_PAIR": "1"}, {"HH_BB32": "tile"}, {"HH_NO_FUSION_MERGE": "1"}, {"HH_NO_BB64": "1"}, {"HH_BB128": "all"}, {"HH_BB128": "stage2"},
+           {"HH_BB32": "tile", "HH_FULL_JOIN": "1"}, {"HH_NO_BB64": "1", "HH_NO_FUSION_MERGE": "1"}]
+    nets = []
+    for env in exact + own:
+        with _switch_env(env):
+            nets.append((env, _net(pkg, 32, 0)[0]))
+    other = pkg.HigherHRNet(17, 48)  # a different architecture between them: other weights, other workspace
+    other.load_state_dict({k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 3)) for k, v in other.state_dict().items()})
+    other.to(DEV).eval()
+    xo = torch.from_numpy(pkg.synth.synth_images(2, 128, 192, 5)).to(DEV)
+    refo = [t.clone() for t in other.forward_raw(xo)]
+    own_ref = {}
+    order = list(range(len(nets)))
+    rng = np.random.default_rng(0)
+    for rnd in range(50):
+        rng.shuffle(order)
+        for i in order:
+            env, net = nets[i]
+            for x, ref, nm in ((x1, ref1, "B=1"), (xb, ref4, "B=4")) if (rnd + i) % 2 else ((xb, ref4, "B=4"), (x1, ref1, "B=1")):
+                got = net.forward_raw(x)
+                if i >= len(exact):
+                    ref = own_ref.setdefault((i, nm), [t.clone() for t in got])
+                for a, b, name in zip(got, ref, ("init_heatmaps", "deconv_heatmaps")):
+                    _same_bits(a, b, f"round {rnd} handle {i} {env} {nm} {name}")
+        if rnd % 10 == 0:
+            for a, b in zip(other.forward_raw(xo), refo):
+                _same_bits(a, b, f"round {rnd} W48 handle")
+
+
 def test_forward_full_size_samples_and_batch_consistency(pkg, net_golden):
     net, _ = _net(pkg, 32, 0)
     x1 = torch.from_numpy(pkg.synth.synth_images(1, 512, 512, 7)).to(DEV)
@@ -225,7 +298,9 @@ def test_forward_full_size_samples_and_batch_consistency(pkg, net_golden):
     xb[0] = x1[0]
     xb[3] = x1[0]
     hb, tb = net(xb)
-    assert torch.equal(hb[0][0], hms[0][0]) and torch.equal(hb[1][3], hms[1][0]) and torch.equal(tb[3], tags[0])
+    _same_bits(hb[0][0], hms[0][0], "hm_q, slot 0 of a batch of 4 vs batch of 1")
+    _same_bits(hb[1][3], hms[1][0], "hm_h, slot 3 of a batch of 4 vs batch of 1")
+    _same_bits(tb[3], tags[0], "tags, slot 3 of a batch of 4 vs batch of 1")
 
 
 def test_flip_tta_vs_reference_golden(pkg):
