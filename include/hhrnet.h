@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define HH_ABI_VERSION 2
+#define HH_ABI_VERSION 3
 #define HH_DTYPE_BF16 1 /* bf16 MFMA operands, fp32 accumulate, bf16 NHWC activations */
 #define HH_DTYPE_FP8 2  /* OCP e4m3 MFMA operands (v_mfma_f32_32x32x64_f8f6f4), fp32 accumulate, e4m3 NHWC activations with one
                            scale per tensor, e4m3 weights with one scale per output channel; needs hh_calibrate (BASELINE.json
@@ -131,8 +131,9 @@ int hh_tap_read(hh_net *net, int index, float *host_nchw);        /* synchronous
 
 /* InferenceKeypointsModel.prepare_input on the device (keypoints/model.py:70-76; resize-align warp of
  * base/transforms/utils.py:89-97): `image_hwc` uint8 RGB [h,w,3] (device), `dst_to_src` the INVERSE of the 2x3 affine
- * that get_affine_transform returns (cv2.warpAffine maps every destination pixel back), output fp32 NCHW [3,H,W] = Normalize(ToTensor(warpAffine(image))).  Bilinear,
- * constant-0 border, intermediate rounded to uint8 as cv2 does (float weights, not cv2's fixed-point tables). */
+ * that get_affine_transform returns (cv2.warpAffine maps every destination pixel back; hh_invert_affine), output fp32 NCHW [3,H,W] = Normalize(ToTensor(warpAffine(image))).
+ * The warp is OpenCV 4.9's 8-bit INTER_LINEAR path restated (fixed-point coordinates and weights, see hh_warp_affine_u8);
+ * parity with cv2 itself is UNPINNED (no cv2 in the build or run images): checked against oracle/transforms.py. */
 int hh_preprocess_u8(const unsigned char *image_hwc, int h, int w, const double dst_to_src[6], float *out_nchw, int H, int W,
                      const float mean[3], const float stdv[3], void *stream);
 
@@ -289,9 +290,24 @@ int hh_resize_accumulate(const float *src, int64_t src_bstride, int B, int K, in
  * Synchronous; for parity tests.                                                        */
 int hh_decoder_read_topk(hh_decoder *dec, float *tags_k, int32_t *coords_k, float *scores_k);
 
+/* get_affine_transform(center, scale, rot=0, output_size, inverse) of base/transforms/utils.py:25-57 -> the 2x3 matrix
+ * (row-major, 6 doubles) cv2.getAffineTransform returns for the reference's three float32 point pairs: the 6x6 system solved
+ * by OpenCV's own LU in float64.  Only scale[0] enters (the reference ignores scale_h).  Host-side. */
+int hh_get_affine_transform(double center_x, double center_y, double scale_w, double dst_w, double dst_h, int inverse, double out[6]);
+
+/* The destination -> source matrix cv2.warpAffine builds from a forward 2x3 matrix (no WARP_INVERSE_MAP), same operation
+ * order; what hh_preprocess_u8 / hh_warp_affine_u8 take as `dst_to_src`.  Host-side. */
+int hh_invert_affine(const double m[6], double out[6]);
+
+/* cv2.warpAffine(image, M, (W, H)) itself, uint8 HWC in and out on the device (resize_align_multi_scale,
+ * base/transforms/utils.py:89-97): OpenCV's fixed-point bilinear (10-bit coordinates, 5-bit fractions, int16 weights summing to
+ * 32768, (v + 2^14) >> 15), constant-0 border. */
+int hh_warp_affine_u8(const unsigned char *image_hwc, int h, int w, const double dst_to_src[6], unsigned char *out_hwc, int H, int W,
+                      void *stream);
+
 /* get_final_kpts_coords / transform_coords: keypoints/results.py:158-171,189-201 with
- * get_affine_transform(inverse=True, rot=0) (base/transforms/utils.py:25-57). Host-side,
- * float64: xy_out[i] = (xy_in[i] - dst/2) * scale_w/dst_w + center.                      */
+ * get_affine_transform(inverse=True, rot=0) (hh_get_affine_transform). Host-side,
+ * float64: xy_out[i] = M @ (xy_in[i], 1) as affine_transform (base/transforms/utils.py:5-8). */
 int hh_transform_coords(const float *xy_in, int n, double center_x, double center_y, double scale_w, double dst_w,
                         double dst_h, double *xy_out);
 

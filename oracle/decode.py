@@ -136,13 +136,10 @@ def decode(hm_q, hm_h, tags_list, **kw):
 
 
 def transform_coords(xy, center, scale, hm_size):
-    """results.py:158-171 with get_affine_transform(inverse=True), rot=0 (PARITY UNPINNED: cv2)."""
-    xy = _f32(xy).reshape(-1, 2)
-    out = np.empty((xy.shape[0], 2), np.float64)
-    lib().orc_transform_coords(_p(xy, C.c_float), xy.shape[0], C.c_double(center[0]), C.c_double(center[1]),
-                               C.c_double(scale[0]), C.c_double(hm_size[0]), C.c_double(hm_size[1]),
-                               _p(out, C.c_double))
-    return out
+    """results.py:158-171 with get_affine_transform(inverse=True), rot=0: oracle/transforms.py (cv2.getAffineTransform's LU solve
+    restated; PARITY UNPINNED: no cv2).  [..., 2] float32 in, float32 [-1, 2] out like the reference's in-place float32 rows."""
+    from . import transforms
+    return transforms.transform_coords(_f32(xy).reshape(-1, 2), center, scale, hm_size)
 
 
 def get_multi_scale_size(h: int, w: int, input_size: int, current_scale: float, min_scale: float):

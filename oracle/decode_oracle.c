@@ -438,18 +438,3 @@ int orc_parse(const float *hm_full, const float *tags_full, int K, int H, int W,
     return fallback ? -P : P;
 }
 
-/* ---------------------------------------------------------------- coordinate un-warp */
-/* results.py:158-171,189-201 + base/transforms/utils.py:25-57 with rot=0, inverse=True.
-   cv2.getAffineTransform solves the 3-point system exactly; with rot=0 the three source /
-   destination points are (c), (c + (0,-s/2)), (c + (-s/2... 90deg)) so the map is the
-   isotropic similarity below (only scale[0] and output_size[0] enter the ratio, on both
-   axes).  PARITY UNPINNED for this function: cv2 is absent from the build container. */
-void orc_transform_coords(const float *xy_in, int n, double cx, double cy, double scale_w, double dst_w, double dst_h,
-                          double *xy_out)
-{
-    double r = scale_w / dst_w;
-    for (int i = 0; i < n; ++i) {
-        xy_out[2 * i + 0] = ((double)xy_in[2 * i + 0] - dst_w * 0.5) * r + cx;
-        xy_out[2 * i + 1] = ((double)xy_in[2 * i + 1] - dst_h * 0.5) * r + cy;
-    }
-}

@@ -96,6 +96,9 @@ def _sig(lib):
         "hh_resize_accumulate": (i32, [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, C.c_float, i32, vp]),
         "hh_decoder_read_topk": (i32, [vp, vp, vp, vp]),
         "hh_transform_coords": (i32, [vp, i32, dbl, dbl, dbl, dbl, dbl, vp]),
+        "hh_get_affine_transform": (i32, [dbl, dbl, dbl, dbl, dbl, i32, C.POINTER(C.c_double)]),
+        "hh_invert_affine": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "hh_warp_affine_u8": (i32, [vp, i32, i32, C.POINTER(C.c_double), vp, i32, i32, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -134,7 +137,7 @@ def load() -> C.CDLL:
                     fcntl.flock(lock, fcntl.LOCK_UN)
         lib = C.CDLL(SO)
         _sig(lib)
-        if lib.hh_abi_version() != 2:
+        if lib.hh_abi_version() != 3:
             raise HHError("libhhrnet.so ABI version mismatch")
         _lib = lib
     return _lib

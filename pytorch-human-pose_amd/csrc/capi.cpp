@@ -1,4 +1,5 @@
 // extern "C" surface declared in include/hhrnet.h (network part).
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -475,13 +476,105 @@ int hh_flip_merge(float *hm, int64_t hm_bstride, const float *hm_flipped, int64_
     return 0;
 }
 
+// cv::solve(A, b, DECOMP_LU) for the 6x6 system of cv::getAffineTransform: OpenCV's own LU (matrix_decomp.cpp LUImpl: partial
+// pivoting on the largest magnitude, first one wins; eliminate with alpha = A[j][i] * (-1 / A[i][i]); back-substitute), which is
+// what hal::LU64f runs for matrices this small.  Every product and sum rounded on its own.
+#pragma clang fp contract(off)
+static int lu_solve6(double A[6][6], double b[6])
+{
+    const int m = 6;
+    const double eps = 2.220446049250313e-16 * 100;
+    for (int i = 0; i < m; ++i) {
+        int k = i;
+        for (int j = i + 1; j < m; ++j)
+            if (std::fabs(A[j][i]) > std::fabs(A[k][i])) k = j;
+        if (std::fabs(A[k][i]) < eps) return 1;
+        if (k != i) {
+            for (int j = i; j < m; ++j) std::swap(A[i][j], A[k][j]);
+            std::swap(b[i], b[k]);
+        }
+        const double d = -1 / A[i][i];
+        for (int j = i + 1; j < m; ++j) {
+            const double alpha = A[j][i] * d;
+            for (int c = i + 1; c < m; ++c) A[j][c] += alpha * A[i][c];
+            b[j] += alpha * b[i];
+        }
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        double sres = b[i];
+        for (int k = i + 1; k < m; ++k) sres -= A[i][k] * b[k];
+        b[i] = sres / A[i][i];
+    }
+    return 0;
+}
+
+int hh_get_affine_transform(double cx, double cy, double scale_w, double dst_w, double dst_h, int inverse, double out[6])
+{
+#pragma clang fp contract(off)
+    // the three point pairs of get_affine_transform(center, scale, rot=0, output_size) as the reference's numpy code leaves them
+    // in its float32 arrays (base/transforms/utils.py:37-53): [center, center + (0, -scale_w/2), third], [dst centre, dst centre +
+    // (0, -dst_w/2), third]; third = b + (-(a-b).y, (a-b).x) in float32
+    float src[3][2], dst[3][2];
+    src[0][0] = (float)cx; src[0][1] = (float)cy;
+    src[1][0] = (float)(cx + 0.0); src[1][1] = (float)(cy + (-scale_w / 2));
+    const float dst_dir_y = (float)(-dst_w / 2);
+    dst[0][0] = (float)(dst_w * 0.5); dst[0][1] = (float)(dst_h * 0.5);
+    dst[1][0] = (float)(dst_w * 0.5 + 0.0); dst[1][1] = (float)(dst_h * 0.5 + (double)dst_dir_y);
+    auto third = [](float p[3][2]) {
+        const float dx = p[0][0] - p[1][0], dy = p[0][1] - p[1][1];
+        p[2][0] = p[1][0] + (-dy);
+        p[2][1] = p[1][1] + dx;
+    };
+    third(src); third(dst);
+    float (*from)[2] = inverse ? dst : src, (*to)[2] = inverse ? src : dst;
+    double A[6][6] = {}, b[6];
+    for (int i = 0; i < 3; ++i) {  // cv::getAffineTransform (imgwarp.cpp): rows (x y 1 0 0 0), (0 0 0 x y 1)
+        A[2 * i][0] = A[2 * i + 1][3] = from[i][0];
+        A[2 * i][1] = A[2 * i + 1][4] = from[i][1];
+        A[2 * i][2] = A[2 * i + 1][5] = 1;
+        b[2 * i] = to[i][0];
+        b[2 * i + 1] = to[i][1];
+    }
+    if (lu_solve6(A, b)) { hh_set_error("hh_get_affine_transform: degenerate point set (scale_w or dst_w is 0)"); return 1; }
+    for (int i = 0; i < 6; ++i) out[i] = b[i];
+    return 0;
+}
+
+int hh_invert_affine(const double m[6], double out[6])
+{
+#pragma clang fp contract(off)
+    // cv::warpAffine without WARP_INVERSE_MAP (imgwarp.cpp), same order of operations
+    double M[6];
+    for (int i = 0; i < 6; ++i) M[i] = m[i];
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D;
+    M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5];
+    const double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    for (int i = 0; i < 6; ++i) out[i] = M[i];
+    return 0;
+}
+
+int hh_warp_affine_u8(const unsigned char *image_hwc, int h, int w, const double dst_to_src[6], unsigned char *out_hwc, int H, int W, void *stream)
+{
+    if (!image_hwc || !out_hwc || h <= 0 || w <= 0 || H <= 0 || W <= 0) { hh_set_error("hh_warp_affine_u8: bad argument"); return 1; }
+    HH_CHECK_HIP(launch_warp_affine_u8(image_hwc, h, w, dst_to_src, out_hwc, H, W, (hipStream_t)stream));
+    return 0;
+}
+
 int hh_transform_coords(const float *xy_in, int n, double cx, double cy, double scale_w, double dst_w, double dst_h,
                         double *xy_out)
 {
-    const double r = scale_w / dst_w;
-    for (int i = 0; i < n; ++i) {
-        xy_out[2 * i + 0] = ((double)xy_in[2 * i + 0] - dst_w * 0.5) * r + cx;
-        xy_out[2 * i + 1] = ((double)xy_in[2 * i + 1] - dst_h * 0.5) * r + cy;
+#pragma clang fp contract(off)
+    double M[6];
+    if (hh_get_affine_transform(cx, cy, scale_w, dst_w, dst_h, 1, M)) return 1;
+    for (int i = 0; i < n; ++i) {  // affine_transform (base/transforms/utils.py:5-8): M @ (x, y, 1) in float64
+        const double x = (double)xy_in[2 * i + 0], y = (double)xy_in[2 * i + 1];
+        xy_out[2 * i + 0] = M[0] * x + M[1] * y + M[2] * 1.0;
+        xy_out[2 * i + 1] = M[3] * x + M[4] * y + M[5] * 1.0;
     }
     return 0;
 }

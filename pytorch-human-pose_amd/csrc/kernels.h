@@ -245,6 +245,7 @@ struct HHImageDesc {  // one raw image of a batch (hh_image_desc of include/hhrn
 };
 hipError_t launch_preprocess_batch(const unsigned char *base, const HHImageDesc *descs, int n, float *out, int H, int W,
                                    const float mean[3], const float stdv[3], hipStream_t s);
+hipError_t launch_warp_affine_u8(const unsigned char *img, int h, int w, const double inv[6], unsigned char *out, int H, int W, hipStream_t s);
 hipError_t launch_preprocess(const unsigned char *img, int h, int w, const double inv[6], float *out, int H, int W,
                              const float mean[3], const float stdv[3], hipStream_t s);
 hipError_t launch_flip_images(const float *in, float *out, int B, int C, int H, int W, hipStream_t s);

@@ -266,27 +266,62 @@ hipError_t launch_linear(const float *x, const float *w, const float *bias, floa
     return hipGetLastError();
 }
 
-// InferenceKeypointsModel.prepare_input on the GPU (keypoints/model.py:70-76 + base/transforms/utils.py:89-97):
-// inverse-mapped bilinear affine warp of a uint8 HWC image with a constant-0 border, rounded to uint8 like
-// cv2.warpAffine's output, then ToTensor (/255) and Normalize -> fp32 NCHW.  float64 coordinates/weights so the
-// result is identical to keypoints/transforms_utils.py::warp_affine (the host restatement).
+// InferenceKeypointsModel.prepare_input on the GPU (keypoints/model.py:70-76 + base/transforms/utils.py:89-97): the resize-align
+// warp as cv2.warpAffine computes it for 8-bit images (OpenCV 4.9 imgwarp.cpp, INTER_LINEAR, BORDER_CONSTANT 0; restated
+// independently in oracle/transforms.py), then ToTensor (/255) and Normalize -> fp32 NCHW.
+//   `inv` is the destination -> source matrix cv::warpAffine builds for itself (hh_invert_affine).  Source coordinates are fixed
+//   point with AB_BITS = 10: adelta = round(M0*x*1024), X0 = round((M1*y + M2)*1024) + 16, X = (X0 + adelta) >> 5; pixel = X >> 5,
+//   fraction = X & 31 (INTER_BITS = 5); weights = the int16 table entries (32-fy)(32-fx)*32 ... that sum to 32768 (entry (0,0):
+//   32767 + 1 on the bottom-right tap, as the table builder leaves it); value = (sum + 16384) >> 15; taps outside the image are 0.
+//   Every double product / sum is rounded on its own (no contraction), round = nearest-even as cvRound.
+__device__ __forceinline__ void warp_pixel_u8(const unsigned char *__restrict__ img, int h, int w, const double inv[6], int x, int y, int out[3])
+{
+    auto sat_i = [](double v) -> int { return v >= 2147483647.0 ? 2147483647 : v <= -2147483648.0 ? (int)(-2147483647 - 1) : (int)v; };
+    const int adelta = sat_i(rint(__dmul_rn(__dmul_rn(inv[0], (double)x), 1024.0)));
+    const int bdelta = sat_i(rint(__dmul_rn(__dmul_rn(inv[3], (double)x), 1024.0)));
+    const int X0 = sat_i(rint(__dmul_rn(__dadd_rn(__dmul_rn(inv[1], (double)y), inv[2]), 1024.0))) + 16;
+    const int Y0 = sat_i(rint(__dmul_rn(__dadd_rn(__dmul_rn(inv[4], (double)y), inv[5]), 1024.0))) + 16;
+    const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    const int sx = min(max(X >> 5, -32768), 32767), sy = min(max(Y >> 5, -32768), 32767);
+    const int fx = X & 31, fy = Y & 31;
+    int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    if ((fx | fy) == 0) { w00 = 32767; w11 = 1; }
+    const bool y0 = sy >= 0 && sy < h, y1 = sy + 1 >= 0 && sy + 1 < h, x0 = sx >= 0 && sx < w, x1 = sx + 1 >= 0 && sx + 1 < w;
+    const unsigned char *r0 = img + ((size_t)(y0 ? sy : 0) * w) * 3, *r1 = img + ((size_t)(y1 ? sy + 1 : 0) * w) * 3;
+    const int c0 = (x0 ? sx : 0) * 3, c1 = (x1 ? sx + 1 : 0) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int p00 = (y0 && x0) ? r0[c0 + c] : 0, p01 = (y0 && x1) ? r0[c1 + c] : 0;
+        const int p10 = (y1 && x0) ? r1[c0 + c] : 0, p11 = (y1 && x1) ? r1[c1 + c] : 0;
+        out[c] = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + 16384) >> 15;
+    }
+}
 __device__ __forceinline__ void preprocess_pixel(const unsigned char *__restrict__ img, int h, int w, const double inv[6],
                                                  float *__restrict__ out, int H, int W, int i, const float mean[3], const float stdv[3])
 {
-    const int y = i / W, x = i % W;
-    const double sx = inv[0] * x + inv[1] * y + inv[2], sy = inv[3] * x + inv[4] * y + inv[5];
-    const double fx0 = floor(sx), fy0 = floor(sy);
-    const long x0 = (long)fx0, y0 = (long)fy0;
-    const double fx = sx - fx0, fy = sy - fy0;
+    int v[3];
+    warp_pixel_u8(img, h, w, inv, i % W, i / W, v);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        auto tap = [&](long yy, long xx) -> double {
-            return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (double)(float)img[((size_t)yy * w + xx) * 3 + c] : 0.0;
-        };
-        const double v = (tap(y0, x0) * (1 - fx) + tap(y0, x0 + 1) * fx) * (1 - fy) + (tap(y0 + 1, x0) * (1 - fx) + tap(y0 + 1, x0 + 1) * fx) * fy;
-        const float u8 = (float)fmin(fmax(rint(v), 0.0), 255.0);
-        out[(size_t)c * H * W + i] = (u8 / 255.0f - mean[c]) / stdv[c];
-    }
+    for (int c = 0; c < 3; ++c) out[(size_t)c * H * W + i] = ((float)v[c] / 255.0f - mean[c]) / stdv[c];
+}
+// resize_align_multi_scale's image itself (uint8 HWC), for callers that want the warped pixels (base/transforms/utils.py:89-97)
+__global__ __launch_bounds__(256) void warp_affine_u8_kernel(const unsigned char *__restrict__ img, int h, int w, double i00, double i01,
+                                                             double i02, double i10, double i11, double i12, unsigned char *__restrict__ out,
+                                                             int H, int W)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const double inv[6] = {i00, i01, i02, i10, i11, i12};
+    int v[3];
+    warp_pixel_u8(img, h, w, inv, i % W, i / W, v);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(size_t)i * 3 + c] = (unsigned char)v[c];
+}
+hipError_t launch_warp_affine_u8(const unsigned char *img, int h, int w, const double inv[6], unsigned char *out, int H, int W, hipStream_t s)
+{
+    hipLaunchKernelGGL(warp_affine_u8_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, img, h, w, inv[0], inv[1], inv[2], inv[3], inv[4],
+                       inv[5], out, H, W);
+    return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char *__restrict__ img, int h, int w, double i00, double i01,
                                                          double i02, double i10, double i11, double i12, float *__restrict__ out,

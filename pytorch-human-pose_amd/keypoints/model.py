@@ -15,7 +15,7 @@ from .grouping import MPPEHeatmapParser
 from .results import InferenceKeypointsResult, transform_coords
 import ctypes as C
 
-from .transforms_utils import COCO_FLIP_INDEX, IMAGENET_MEAN, IMAGENET_STD, affine_matrix, get_multi_scale_size
+from .transforms_utils import COCO_FLIP_INDEX, IMAGENET_MEAN, IMAGENET_STD, dst_to_src_matrix, get_multi_scale_size
 
 COCO_LIMBS = [(15, 13), (13, 11), (16, 14), (14, 12), (11, 12), (5, 11), (6, 12), (5, 6), (5, 7), (6, 8), (7, 9), (8, 10),
               (1, 2), (0, 1), (0, 2), (1, 3), (2, 4), (3, 5), (4, 6)]
@@ -193,8 +193,7 @@ class InferenceKeypointsModel:
     def prepare_input_scaled(self, image: np.ndarray, current_scale: float, min_scale: float):
         """prepare_input for one entry of a multi-scale test (get_multi_scale_size, base/transforms/utils.py:60-86)."""
         size, center, scale = get_multi_scale_size(image, self.input_size, current_scale, min_scale)
-        fwd = np.vstack([affine_matrix(center, scale, size), [0, 0, 1]])
-        m = np.ascontiguousarray(np.linalg.inv(fwd)[:2], dtype=np.float64)
+        m = dst_to_src_matrix(center, scale, size)
         raw = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8)).to(self.device)
         x = torch.empty((1, 3, size[1], size[0]), device=self.device, dtype=torch.float32)
         stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -242,8 +241,7 @@ class InferenceKeypointsModel:
         """model.py:70-76: resize-align -> ToTensor -> Normalize -> [1,3,h,w] on device.  Only the raw uint8 image
         crosses PCIe; warp + normalisation run in hh_preprocess_u8."""
         size, center, scale = get_multi_scale_size(image, self.input_size, 1, 1)
-        fwd = np.vstack([affine_matrix(center, scale, size), [0, 0, 1]])
-        m = np.ascontiguousarray(np.linalg.inv(fwd)[:2], dtype=np.float64)  # destination -> source, as warp_affine()
+        m = dst_to_src_matrix(center, scale, size)  # destination -> source, as cv2.warpAffine inverts the forward matrix
         raw = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8)).to(self.device)
         x = torch.empty((1, 3, size[1], size[0]), device=self.device, dtype=torch.float32)
         stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -305,8 +303,7 @@ class InferenceKeypointsModel:
     @staticmethod
     def _dst_to_src(size, center, scale) -> np.ndarray:
         """The destination -> source 2x3 matrix of the resize-align warp (what cv2.warpAffine inverts for itself)."""
-        fwd = np.vstack([affine_matrix(center, scale, size), [0, 0, 1]])
-        return np.ascontiguousarray(np.linalg.inv(fwd)[:2], dtype=np.float64)
+        return dst_to_src_matrix(center, scale, size)
 
     def _geometry(self, image: np.ndarray):
         """Resize-align geometry of one raw image: ((w, h) of the model input, center, scale, destination->source 2x3 matrix)."""

@@ -1,13 +1,17 @@
 """Inference resize geometry and coordinate un-warp (host side, numpy).
 
-Restates `/root/reference/src/base/transforms/utils.py:5-97`.  `cv2` is not available in
-the build/run images, so `warp_affine` is this repo's own bilinear warp with cv2's
-conventions (inverse map, zero border) but float weights instead of cv2's 5-bit fixed
-point tables: image preprocessing is not bit-identical to opencv 4.9.
+Mirrors `/root/reference/src/base/transforms/utils.py:5-97`.  The OpenCV arithmetic behind it (cv2.getAffineTransform's LU
+solve, cv2.warpAffine's matrix inversion and fixed-point bilinear) runs behind the C-ABI (hh_get_affine_transform,
+hh_invert_affine, hh_warp_affine_u8 / hh_preprocess_u8); `cv2` itself is in neither the build nor the run image, so parity with
+opencv 4.9 is UNPINNED -- the tests compare with the independent restatement in oracle/transforms.py.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
+
+from .. import _lib
 
 COCO_FLIP_INDEX = [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15]  # keypoints/transforms.py:11
 IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], np.float32)  # keypoints/model.py:49
@@ -30,43 +34,47 @@ def get_multi_scale_size(image: np.ndarray, input_size: int, current_scale: floa
 
 
 def affine_matrix(center, scale, output_size, inverse: bool = False) -> np.ndarray:
-    """get_affine_transform(center, scale, rot=0, output_size) (utils.py:25-57): with rot = 0 the
-    three point pairs define an isotropic scale r = dst_w / scale_w about center <-> (dst_w/2, dst_h/2)."""
-    dst_w, dst_h = float(output_size[0]), float(output_size[1])
-    r = dst_w / float(scale[0])
-    if inverse:
-        r = 1.0 / r
-        return np.array([[r, 0.0, center[0] - r * dst_w * 0.5], [0.0, r, center[1] - r * dst_h * 0.5]], np.float64)
-    return np.array([[r, 0.0, dst_w * 0.5 - r * center[0]], [0.0, r, dst_h * 0.5 - r * center[1]]], np.float64)
+    """get_affine_transform(center, scale, rot=0, output_size, inverse) (utils.py:25-57) -> the float64 2x3 matrix
+    cv2.getAffineTransform returns for the reference's float32 point pairs (hh_get_affine_transform: OpenCV's 6x6 LU solve;
+    for rot = 0 it is the isotropic scale r = dst_w / scale_w about center <-> (dst_w/2, dst_h/2) up to the solve's rounding)."""
+    m = np.empty(6, np.float64)
+    _lib.check(_lib.load().hh_get_affine_transform(float(center[0]), float(center[1]), float(scale[0]), float(output_size[0]),
+                                                   float(output_size[1]), int(inverse), m.ctypes.data_as(C.POINTER(C.c_double))))
+    return m.reshape(2, 3)
 
 
-def warp_affine(image: np.ndarray, m: np.ndarray, size) -> np.ndarray:
-    """cv2.warpAffine(image, m, size) semantics (m maps src->dst, bilinear, constant-0 border)."""
+def dst_to_src_matrix(center, scale, size) -> np.ndarray:
+    """What cv2.warpAffine(image, get_affine_transform(...), size) does first: the forward matrix inverted in float64 with
+    OpenCV's own formula (hh_invert_affine) -> contiguous float64 [2,3], the `dst_to_src` argument of the preprocessing kernels."""
+    fwd = np.ascontiguousarray(affine_matrix(center, scale, size).reshape(6))
+    inv = np.empty(6, np.float64)
+    dp = C.POINTER(C.c_double)
+    _lib.check(_lib.load().hh_invert_affine(fwd.ctypes.data_as(dp), inv.ctypes.data_as(dp)))
+    return inv.reshape(2, 3)
+
+
+def warp_affine(image: np.ndarray, m: np.ndarray, size, device="cuda:0") -> np.ndarray:
+    """cv2.warpAffine(image, m, size) for uint8 HWC images (m maps src->dst; bilinear, constant-0 border) on the GPU
+    (hh_warp_affine_u8: OpenCV's fixed-point arithmetic).  There is no host fallback."""
+    import torch
     w_out, h_out = int(size[0]), int(size[1])
-    a = np.vstack([m, [0, 0, 1]])
-    inv = np.linalg.inv(a)
-    xs, ys = np.meshgrid(np.arange(w_out, dtype=np.float64), np.arange(h_out, dtype=np.float64))
-    sx = inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]
-    sy = inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]
-    x0 = np.floor(sx).astype(np.int64)
-    y0 = np.floor(sy).astype(np.int64)
-    fx = (sx - x0)[..., None]
-    fy = (sy - y0)[..., None]
-    h, w = image.shape[:2]
-    img = image.astype(np.float32)
-    if img.ndim == 2:
-        img = img[..., None]
-
-    def tap(yy, xx):
-        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
-        v = img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)]
-        return v * ok[..., None]
-
-    out = (tap(y0, x0) * (1 - fx) + tap(y0, x0 + 1) * fx) * (1 - fy) + (tap(y0 + 1, x0) * (1 - fx) + tap(y0 + 1, x0 + 1) * fx) * fy
-    return np.clip(np.rint(out), 0, 255).astype(image.dtype)
+    dp = C.POINTER(C.c_double)
+    fwd = np.ascontiguousarray(np.asarray(m, np.float64).reshape(6))
+    inv = np.empty(6, np.float64)
+    lib = _lib.load()
+    _lib.check(lib.hh_invert_affine(fwd.ctypes.data_as(dp), inv.ctypes.data_as(dp)))
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError("warp_affine: uint8 [h, w, 3] images only")
+    raw = torch.from_numpy(img).to(device)
+    out = torch.empty((h_out, w_out, 3), device=raw.device, dtype=torch.uint8)
+    with torch.cuda.device(raw.device):
+        _lib.check(lib.hh_warp_affine_u8(raw.data_ptr(), img.shape[0], img.shape[1], inv.ctypes.data_as(dp), out.data_ptr(), h_out, w_out,
+                                         torch.cuda.current_stream(raw.device).cuda_stream))
+    return out.cpu().numpy()
 
 
-def resize_align_multi_scale(image: np.ndarray, input_size: int, current_scale: float, min_scale: float):
+def resize_align_multi_scale(image: np.ndarray, input_size: int, current_scale: float, min_scale: float, device="cuda:0"):
     """utils.py:89-97"""
     size, center, scale = get_multi_scale_size(image, input_size, current_scale, min_scale)
-    return warp_affine(image, affine_matrix(center, scale, size), size), center, scale
+    return warp_affine(image, affine_matrix(center, scale, size), size, device), center, scale

@@ -395,7 +395,7 @@ def test_end_to_end_model_call(pkg, synth):
     rj, rs = orc.decode(hms[0][0].cpu().numpy(), hms[1][0].cpu().numpy(), [t[0].cpu().numpy() for t in tags], max_people=30, det_thr=0.05, tag_thr=0.5)
     assert res.kpts_scores.shape == rj.shape[:2] and np.array_equal(res.kpts_scores, rj[..., 2]) and np.array_equal(res.obj_scores, rs)
     exp = orc.transform_coords(rj[..., :2], center, scale, (384, 256)).reshape(rj.shape[0], 17, 2)
-    assert np.allclose(res.kpts_coords, exp, atol=1e-3)
+    assert np.array_equal(res.kpts_coords, exp)  # hh_transform_coords and the oracle restate the same LU solve: same bits
 
 
 def test_classification_hrnet_cfg1_vs_reference_golden(pkg):
@@ -483,20 +483,28 @@ def test_forward_odd_batch_and_repeatability(pkg):
     _close(t1.cpu().numpy(), rt.numpy(), "tags")
 
 
-def test_gpu_preprocessing_matches_host_restatement(pkg):
-    """hh_preprocess_u8 == Normalize(ToTensor(warp_affine(image))) of keypoints/transforms_utils.py, exactly."""
+def test_gpu_preprocessing_matches_oracle_opencv_restatement(pkg):
+    """hh_preprocess_u8 == Normalize(ToTensor(cv2.warpAffine(image, get_affine_transform(...)))) as oracle/transforms.py restates
+    OpenCV 4.9's fixed-point warp (10-bit coordinates, 5-bit fractions, int16 weight table, (v + 2^14) >> 15), bit for bit; the
+    warped uint8 image itself (hh_warp_affine_u8) too.  Parity with cv2 itself stays unpinned (no cv2 here)."""
     import importlib
+    from oracle import transforms as ot
     tu = importlib.import_module(pkg.__name__ + ".keypoints.transforms_utils")
     net, _ = _net(pkg, 32, 0)
     model = pkg.InferenceKeypointsModel(net, input_size=256, device=DEV)
-    for shape in ((200, 300, 3), (301, 177, 3), (256, 256, 3)):
+    for shape in ((200, 300, 3), (301, 177, 3), (256, 256, 3), (97, 411, 3), (480, 640, 3)):
         img = np.random.RandomState(shape[0]).randint(0, 256, shape).astype(np.uint8)
         x, center, scale = model.prepare_input(img)
-        resized, c2, s2 = tu.resize_align_multi_scale(img, 256, 1, 1)
-        ref = (resized.astype(np.float32) / np.float32(255.0) - tu.IMAGENET_MEAN) / tu.IMAGENET_STD
+        ref, resized, c2, s2 = ot.prepare_input(img, 256)
         assert tuple(center) == tuple(c2) and tuple(scale) == tuple(s2)
-        assert x.shape[1:] == (3,) + resized.shape[:2]
-        assert np.array_equal(x[0].cpu().numpy(), np.ascontiguousarray(ref.transpose(2, 0, 1)))
+        assert x.shape[1:] == ref.shape
+        assert np.array_equal(x[0].cpu().numpy(), ref), shape
+        got_u8, c3, s3 = tu.resize_align_multi_scale(img, 256, 1, 1, DEV)
+        assert np.array_equal(got_u8, resized), shape
+    # a rotated / sheared / shifted warp with out-of-image regions on every side (the kernel takes any affine)
+    img = np.random.RandomState(5).randint(0, 256, (90, 130, 3)).astype(np.uint8)
+    for m in ([[0.8, 0.3, -12.5], [-0.25, 1.1, 20.25]], [[1.7, 0, -40], [0, 1.7, -33.3]], [[0.31, -0.05, 7], [0.02, 0.29, 3]]):
+        assert np.array_equal(tu.warp_affine(img, np.array(m), (150, 110), DEV), ot.warp_affine(img, m, (150, 110))), m
     # hh_preprocess_u8_batch: raw images of different sizes (one aspect ratio -> one model-input shape) in one launch, descriptors
     # read from device memory: the same bits as image by image
     import ctypes as C

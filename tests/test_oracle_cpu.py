@@ -32,11 +32,43 @@ def test_multi_scale_size_table():
         assert [float(scale[0]), float(scale[1])] == r["scale"]
 
 
-def test_transform_coords_closed_form():
-    # hand-solved: 640x480 image -> 704x512 input (scale_w = 704/512*480 = 660): centre maps to centre,
-    # one model-input pixel is scale_w/dst_w = 0.9375 raw pixels on both axes.
-    out = orc.transform_coords(np.array([[352.0, 256.0], [353.0, 258.0], [0.0, 0.0]], np.float32), (320, 240), (660.0, 480.0), (704, 512))
-    assert np.allclose(out, [[320, 240], [320.9375, 241.875], [320 - 352 * 0.9375, 240 - 256 * 0.9375]], atol=1e-12)
+def test_opencv_restatement_hand_cases():
+    """oracle/transforms.py restates OpenCV 4.9's published arithmetic; cv2 is not installed, so these are hand-derived cases
+    (the restatement stays PARITY UNPINNED)."""
+    from oracle import transforms as ot
+    tab = ot.bilinear_tab_i().astype(np.int64)
+    assert tab.shape == (1024, 4) and (tab.sum(1) == 32768).all()
+    assert tab[0].tolist() == [32767, 0, 0, 1]                    # the saturated entry and its repair
+    assert tab[16 * 32 + 16].tolist() == [8192] * 4               # (1/2, 1/2)
+    assert tab[8].tolist() == [24576, 8192, 0, 0]                 # fy = 0, fx = 8/32
+    # getAffineTransform: LU solve against numpy's solver on a rotated / sheared triple
+    src = np.array([[10, 20], [200, 35], [40, 180]], np.float32)
+    dst = np.array([[5, 7], [150, 90], [-20, 160]], np.float32)
+    m = ot.cv_get_affine_transform(src, dst)
+    assert np.allclose(m @ np.vstack([src.T.astype(np.float64), np.ones(3)]), dst.T, atol=1e-9)
+    # hand-solved geometry: 640x480 image -> 704x512 input (scale_w = 660): centre to centre, 704/660 input pixels per raw pixel
+    f = ot.get_affine_transform((320, 240), (660.0, 480.0), 0, (704, 512))
+    assert np.allclose(f, [[704 / 660, 0, 352 - 320 * 704 / 660], [0, 704 / 660, 256 - 240 * 704 / 660]], atol=1e-12)
+    out = ot.transform_coords(np.array([[352.0, 256.0], [353.0, 258.0], [0.0, 0.0]], np.float32), (320, 240), (660.0, 480.0), (704, 512))
+    assert out.dtype == np.float32 and np.allclose(out, [[320, 240], [320.9375, 241.875], [320 - 352 * 0.9375, 240 - 256 * 0.9375]], atol=1e-4)
+    # warpAffine: identity and integer shifts reproduce pixels exactly, outside = 0
+    img = np.random.RandomState(0).randint(0, 256, (40, 50, 3)).astype(np.uint8)
+    assert np.array_equal(ot.warp_affine(img, [[1, 0, 0], [0, 1, 0]], (50, 40)), img)
+    sh = ot.warp_affine(img, [[1, 0, 3], [0, 1, -2]], (50, 40))  # dst(x, y) = src(x - 3, y + 2)
+    assert np.array_equal(sh[:38, 3:], img[2:, :47]) and not sh[:, :3].any() and not sh[38:].any()
+    # x2 upscale about the origin of a 1x2 image [0, 200]: dst x -> src x/2; fraction 16/32 at odd x: (0*16384 + 200*16384 + 16384) >> 15 = 100;
+    # at x = 3 the right tap is outside: (200*16384 + 16384) >> 15 = 100; x = 4 is outside altogether
+    line = np.array([[[0, 0, 0], [200, 200, 200]]], np.uint8)
+    up = ot.warp_affine(line, [[2, 0, 0], [0, 1, 0]], (5, 1))
+    assert up[0, :, 0].tolist() == [0, 100, 200, 100, 0]
+    # a quarter-pixel shift: src x = dst x - 0.25 -> X = x*32 - 8: pixel x-1, fraction 24/32: (p[x-1]*8 + p[x]*24)*1024 + 16384 >> 15
+    row = np.array([[[10, 10, 10], [50, 50, 50], [90, 90, 90]]], np.uint8)
+    q = ot.warp_affine(row, [[1, 0, 0.25], [0, 1, 0]], (3, 1))
+    assert q[0, :, 0].tolist() == [(10 * 24 * 1024 + 16384) >> 15, ((10 * 8 + 50 * 24) * 1024 + 16384) >> 15, ((50 * 8 + 90 * 24) * 1024 + 16384) >> 15]
+    # prepare_input: ToTensor + Normalize of the warped image
+    x, resized, center, scale = ot.prepare_input(np.random.RandomState(1).randint(0, 256, (120, 160, 3)).astype(np.uint8), 128)
+    assert x.shape == (3, 128, 192) and x.dtype == np.float32 and resized.shape == (128, 192, 3)
+    assert np.array_equal(x[1], (resized[..., 1].astype(np.float32) / np.float32(255) - np.float32(0.456)) / np.float32(0.224))
 
 
 def test_bilinear_bit_exact_vs_torch_cpu():

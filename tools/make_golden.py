@@ -382,7 +382,122 @@ def train_autocast_fixture():
     print("autocast train fixture: loss", out["loss"], "scale", scale)
 
 
+# ------------------------------------------------------------------ COCO result packing (a19)
+def eval_packing_fixture():
+    """src/keypoints/bin/eval.py:18-49 `evaluate_dataset`, the reference's own function, run on a fake model and a fake dataset.
+    Its module imports third-party packages that are absent here (pycocotools, cv2, torchvision, albumentations, mlflow, ...):
+    none of them is touched by `evaluate_dataset`, so empty stand-in MODULE OBJECTS (attribute access yields a dummy class) satisfy
+    the import lines; the code that runs and is pinned is the reference's packing loop, byte for byte."""
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return _Dummy()
+
+        def __getattr__(self, name):
+            return _Dummy()
+
+        def __mro_entries__(self, bases):
+            return (object,)
+
+        def __iter__(self):
+            return iter(())
+
+        def __getitem__(self, k):  # typing-style subscripts (Generic[T], Callable[..., X])
+            return _Dummy()
+
+        def __or__(self, other):
+            return _Dummy()
+
+        __ror__ = __or__
+
+    class _Stub(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return _Dummy()
+
+    import importlib.abc
+    import importlib.machinery
+
+    absent = ("pycocotools", "cv2", "torchvision", "albumentations", "mlflow", "colorlog", "natsort", "seaborn", "pynvml", "torchinfo",
+              "thop", "dacite", "geda", "onnx", "onnxruntime", "plotly", "matplotlib", "PIL", "imageio", "moviepy", "pandas", "scipy",
+              "skimage", "sklearn", "yaml", "psutil", "GPUtil", "rich", "dotenv", "git", "joblib", "gdown", "ffmpeg", "kaleido")
+
+    class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, name, path=None, target=None):
+            top = name.split(".")[0]
+            if top in absent:
+                try:  # installed for real? then use it
+                    for f in sys.meta_path:
+                        if f is self:
+                            continue
+                        sp = f.find_spec(name, path, target) if hasattr(f, "find_spec") else None
+                        if sp is not None and sp.origin not in (None, "namespace"):  # (a bare directory of that name is not the package)
+                            return sp
+                except Exception:  # noqa: BLE001
+                    pass
+                return importlib.machinery.ModuleSpec(name, self, is_package=True)
+            return None
+
+        def create_module(self, spec):
+            return _Stub(spec.name)
+
+        def exec_module(self, module):
+            pass
+
+    sys.meta_path.insert(0, _Finder())
+    from src.keypoints.bin.eval import evaluate_dataset
+
+    rs = np.random.RandomState(11)
+    people = [3, 0, 1, 30]
+    stems = ["000000000139", "000000397133", "000000000785", "100000000001"]
+    cases = []
+    for n in people:
+        coords = (rs.uniform(-20, 700, (n, 17, 2))).astype(np.float32)   # what transform_coords leaves: float32 raw-image pixels
+        scores = rs.uniform(0.01, 1.0, (n,)).astype(np.float32)           # person scores (grouping.py:276), float32
+        cases.append((coords, scores))
+
+    class Result:
+        def __init__(self, c, s):
+            self.kpts_coords, self.obj_scores = c, s
+
+    class Model:
+        def __init__(self):
+            self.i = 0
+
+        def __call__(self, raw_image, annot=None):
+            assert annot is None and raw_image.shape == (8, 8, 3)
+            r = Result(*cases[self.i])
+            self.i += 1
+            return r
+
+    class Dataset:
+        images_filepaths = [f"/data/COCO/images/val2017/{s}.jpg" for s in stems]
+
+        def __len__(self):
+            return len(stems)
+
+        def load_image(self, idx):
+            return np.zeros((8, 8, 3), np.uint8)
+
+    results = evaluate_dataset(Model(), Dataset())
+    assert len(results) == sum(people)
+    np.savez_compressed(os.path.join(OUT, "eval_packing_inputs.npz"), stems=np.array(stems),
+                        **{f"coords{i}": c for i, (c, _) in enumerate(cases)}, **{f"scores{i}": s for i, (_, s) in enumerate(cases)})
+    with open(os.path.join(OUT, "eval_packing.json"), "w") as f:
+        json.dump(results, f)
+    print("eval packing fixture:", len(results), "entries; first", {k: (v if k != "keypoints" else v[:6]) for k, v in results[0].items()})
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["eval_packing"]:
+        eval_packing_fixture()
+        sys.exit(0)
     which = sys.argv[1:] or ["net", "decode", "flip", "munkres", "geometry", "loss", "train", "train_autocast"]
     if "train_autocast" in which:
         train_autocast_fixture()
