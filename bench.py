@@ -241,6 +241,9 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="w32_b32_512",
                     help="BASELINE.json workload: w32_b32_512 = configs[1] (headline), fp8_w48_b64_640 = configs[4]; bf16_w48_b64_640 = that workload on the bf16 path")
     ap.add_argument("--people", type=int, default=10)
+    ap.add_argument("--dense-people", type=int, default=27,
+                    help="people per image of the second, dense set of constructed maps whose decode time is reported beside the headline "
+                         "(config.decode_dense_ms; 0 = skip): the 10-people maps of SURVEY.md section 8d understate what a crowded image costs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch probe steps behind the timed loop")
     ap.add_argument("--probe-steps", type=int, default=3, help="serial probe steps behind the timed loop (roofline line)")
@@ -311,6 +314,10 @@ def main():
     tags = torch.from_numpy(np.stack([uniq[i % 8][2] for i in range(B)])).to(dev)
     parser = pkg.MPPEHeatmapParser(K, 30, 0.05, 0.5)
     lib = pkg._lib.load()
+    dense = None
+    if args.dense_people > 0:
+        du = [pkg.synth.synth_decode_maps(K, H // 4, W // 4, args.dense_people, seed=5000 + rank * 8 + i)[:3] for i in range(8)]
+        dense = tuple(torch.from_numpy(np.stack([(du[i % 8][j] if j < 2 else du[i % 8][2][0]) for i in range(B)])).to(dev) for j in range(3))
 
     if args.single_lane:
         lib.hh_set_multi_lane(net._h, 0)
@@ -371,6 +378,17 @@ def main():
                 fn()
             side.synchronize()
             parts.append((time.perf_counter() - t1) / 5)
+        dense_ms = dense_people = None
+        if dense is not None:  # a crowded batch through the same decoder (not part of `value`)
+            fn = lambda: parser.decode_batch_device(dense[0], dense[1], [dense[2]], adjust=True, refine=True)  # noqa: E731
+            dd = fn()
+            side.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                dd = fn()
+            side.synchronize()
+            dense_ms = (time.perf_counter() - t1) / 5 * 1e3
+            dense_people = int(dd[2].sum().item())
     del stream
     num_people = int(dec[2].sum().item())
     assert not bool(dec[3].any().item()), "decode flagged an image (solver guard / no-group fallback) on the bench maps"
@@ -387,6 +405,8 @@ def main():
                 "people_decoded_per_batch": num_people,
                 "forward_ms": round(parts[0] * 1e3, 3),
                 "decode_ms": round(parts[1] * 1e3, 3),
+                "decode_dense_ms": None if dense_ms is None else round(dense_ms, 3),
+                "decode_dense_people_per_batch": dense_people,
                 "forward_tflops": round(net.forward_flops(B, H, W) / parts[0] / 1e12, 1),
                 "streams": "forward (+3 internal branch lanes) and decode on two streams" if args.overlap else
                            "forward (+3 internal branch lanes), then decode, back to back on one stream: step = forward + decode",

@@ -18,6 +18,8 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 template <typename F, int... I>
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fp8_kernel(const Fp8BBParams p)
         pf_setup(pf_more ? tn : t);
 
         unsigned resq[2][4];  // residual: e4m3 x at the lane's two output pixels, couts ct*32 + 8g + 4h .. +3
+        u32x2 resw[2][4];     // ... or, with a bf16 trunk (p.res16), the same couts as bf16 pairs straight from HBM
         // ================= conv1 + bn1 + relu -> intermediate tile (LDS, e4m3) =================
         auto conv1_phase = [&](auto nqc) {
             constexpr int NQ = decltype(nqc)::value;
@@ -265,6 +268,20 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fp8_kernel(const Fp8BBParams p)
                     fb[buf][q][1] = *reinterpret_cast<const u32x4 *>(lds_m + mbase + q * MW * PS + o1);
                 }
             };
+            if (p.res16) {  // in flight under conv2's MFMAs, consumed in its epilogue
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int oy = oy0 + part * 2 + q, ox = ox0 + r;
+                    const bool ok = (oy < p.H) & (ox < p.W);
+                    const bf16_raw *src = p.res16 + (ok ? (((ptrdiff_t)b * p.H + oy) * p.W + ox) * p.res16_cs : 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const bool okc = ok & (ct * 32 + 8 * g < C);
+                        const u32x2 v = *reinterpret_cast<const u32x2 *>(src + (okc ? ct * 32 + 8 * g + 4 * h : 0));
+                        resw[q][g] = okc ? v : u32x2{0u, 0u};
+                    }
+                }
+            }
             ld(std::integral_constant<int, 0>{}, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
             static_for<NSTEP>([&](auto ic) {
@@ -291,6 +308,13 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fp8_kernel(const Fp8BBParams p)
                 for (int g = 0; g < 4; ++g) {
                     const float4 mu = *reinterpret_cast<const float4 *>(lds_c + 2 * COUT_T + ct * 32 + 8 * g + 4 * h);
                     const float4 bs = *reinterpret_cast<const float4 *>(lds_c + 3 * COUT_T + ct * 32 + 8 * g + 4 * h);
+                    if (p.res16) {
+                        y[4 * g + 0] = fmaxf(__builtin_bit_cast(float, resw[q][g][0] << 16) + __builtin_fmaf(acc2[q][4 * g + 0], mu.x, bs.x), 0.f);
+                        y[4 * g + 1] = fmaxf(__builtin_bit_cast(float, resw[q][g][0] & 0xffff0000u) + __builtin_fmaf(acc2[q][4 * g + 1], mu.y, bs.y), 0.f);
+                        y[4 * g + 2] = fmaxf(__builtin_bit_cast(float, resw[q][g][1] << 16) + __builtin_fmaf(acc2[q][4 * g + 2], mu.z, bs.z), 0.f);
+                        y[4 * g + 3] = fmaxf(__builtin_bit_cast(float, resw[q][g][1] & 0xffff0000u) + __builtin_fmaf(acc2[q][4 * g + 3], mu.w, bs.w), 0.f);
+                        continue;
+                    }
                     const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)resq[q][g], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)resq[q][g], true);
                     y[4 * g + 0] = fmaxf(__builtin_fmaf(lo[0], p.res_scale, __builtin_fmaf(acc2[q][4 * g + 0], mu.x, bs.x)), 0.f);
                     y[4 * g + 1] = fmaxf(__builtin_fmaf(lo[1], p.res_scale, __builtin_fmaf(acc2[q][4 * g + 1], mu.y, bs.y)), 0.f);
@@ -302,6 +326,29 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fp8_kernel(const Fp8BBParams p)
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
                         if (ct * 32 + 8 * (i >> 2) < C) amax_out = fmaxf(amax_out, y[i]);
+                if (p.out16) {  // the block output as bf16 too (the next block's residual): couts 16h .. 16h+15 after the half exchange
+                    unsigned gd[4][2];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x2 f0 = {y[4 * g + 0], y[4 * g + 1]}, f1 = {y[4 * g + 2], y[4 * g + 3]};
+                        gd[g][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f0, bf16x2));
+                        gd[g][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f1, bf16x2));
+                    }
+                    u32x4 o0, o1;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        auto u02 = __builtin_amdgcn_permlane32_swap(gd[0][d], gd[2][d], false, false);
+                        auto u13 = __builtin_amdgcn_permlane32_swap(gd[1][d], gd[3][d], false, false);
+                        o0[d] = u02[0]; o0[2 + d] = u02[1];
+                        o1[d] = u13[0]; o1[2 + d] = u13[1];
+                    }
+                    const int c16 = ct * 32 + 16 * h;
+                    if (valid && c16 < C) {
+                        u32x4 *dst = reinterpret_cast<u32x4 *>(p.out16 + (((ptrdiff_t)b * p.H + oy) * p.W + ox) * p.out16_cs + c16);
+                        dst[0] = o0;
+                        dst[1] = o1;
+                    }
+                }
                 const u32x4 o = pack_tile_fp8(y, p.out_inv_scale);
                 const int c0 = ct * 32 + 16 * h;
                 if (valid && c0 < C) *reinterpret_cast<u32x4 *>(p.out + (((ptrdiff_t)b * p.H + oy) * p.W + ox) * p.out_cs + c0) = o;

@@ -20,6 +20,7 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 template <typename F, int... I>
@@ -143,7 +144,24 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(const Fp8ConvParams p)
     // the residual (fp8, 16 bytes = couts 16h..16h+15 of the lane's pixel and cout tile) is fetched now and consumed in
     // the epilogue
     u32x4 rv[PT][NT];
-    if (p.res) {
+    u32x4 rw[PT][NT][2];  // bf16 residual: couts 16h .. 16h+7 and 16h+8 .. 16h+15 of the lane's pixel and cout tile
+    if (p.res16) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int oy = oy0 + (wave * PT + pt) * RPT + dy, ox = ox0 + dx;
+            const bool valid = oy < p.Ho && ox < p.Wo;
+            const size_t pix = valid ? ((size_t)b * p.Hob + (oy * p.osy + ooy)) * p.Wob + (ox * p.osx + oox) : 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c0 = cg * COUT_T + nt * 32 + 16 * h;
+                const bool ok = valid && c0 < p.cout_store;
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(p.res16 + pix * p.res16_cs + p.res16_coff + (ok ? c0 : 0));
+                const u32x4 v0 = src[0], v1 = src[1];
+                rw[pt][nt][0] = ok ? v0 : u32x4{0u, 0u, 0u, 0u};
+                rw[pt][nt][1] = ok ? v1 : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    } else if (p.res) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int oy = oy0 + (wave * PT + pt) * RPT + dy, ox = ox0 + dx;
@@ -246,7 +264,21 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(const Fp8ConvParams p)
                 y[4 * g + 0] = __builtin_fmaf(acc[nt][pt][4 * g + 0], mu.x, bs.x); y[4 * g + 1] = __builtin_fmaf(acc[nt][pt][4 * g + 1], mu.y, bs.y);
                 y[4 * g + 2] = __builtin_fmaf(acc[nt][pt][4 * g + 2], mu.z, bs.z); y[4 * g + 3] = __builtin_fmaf(acc[nt][pt][4 * g + 3], mu.w, bs.w);
             }
-            if (p.res) {
+            if (p.res16) {
+                // 2 x 16 bytes = couts 16h .. 16h+15 as bf16 -> the accumulator layout (group g = couts 8g + 4h .. +3 = two dwords):
+                // the exchange of the bf16 store path below, backwards: (g0, g2) = swap(dwords 0-1, 2-3), (g1, g3) = swap(4-5, 6-7)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    auto u02 = __builtin_amdgcn_permlane32_swap(rw[pt][nt][0][d], rw[pt][nt][0][2 + d], false, false);
+                    auto u13 = __builtin_amdgcn_permlane32_swap(rw[pt][nt][1][d], rw[pt][nt][1][2 + d], false, false);
+                    const unsigned g4[4] = {u02[0], u13[0], u02[1], u13[1]};  // dword d of groups 0, 1, 2, 3
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        y[4 * g + 2 * d + 0] += __builtin_bit_cast(float, g4[g] << 16);
+                        y[4 * g + 2 * d + 1] += __builtin_bit_cast(float, g4[g] & 0xffff0000u);
+                    }
+                }
+            } else if (p.res) {
                 // 16 bytes = couts 16h .. 16h+15  ->  the accumulator layout (couts 8g + 4h + i): the two exchanges of the
                 // store path, backwards
                 auto t0 = __builtin_amdgcn_permlane32_swap(rv[pt][nt][0], rv[pt][nt][2], false, false);
@@ -290,6 +322,30 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(const Fp8ConvParams p)
                 const int c0 = cg * COUT_T + nt * 32 + 16 * h;
                 if (valid && c0 < p.cout_store)
                     *reinterpret_cast<u32x4 *>(p.out + pix * p.out_cs + p.out_coff + c0) = u32x4{a0[0], a1[0], a0[1], a1[1]};
+            }
+            if (p.out16) {  // the same values as bf16: group g (couts 8g + 4h .. +3) = two dwords; (g0, g2) and (g1, g3) exchanged between the
+                            // lane halves leave couts 16h .. 16h+15 contiguous in the lane: two 16-byte stores
+                unsigned gd[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x2 f0 = {y[4 * g + 0], y[4 * g + 1]}, f1 = {y[4 * g + 2], y[4 * g + 3]};
+                    gd[g][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f0, bf16x2));
+                    gd[g][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f1, bf16x2));
+                }
+                u32x4 o0, o1;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    auto u02 = __builtin_amdgcn_permlane32_swap(gd[0][d], gd[2][d], false, false);
+                    auto u13 = __builtin_amdgcn_permlane32_swap(gd[1][d], gd[3][d], false, false);
+                    o0[d] = u02[0]; o0[2 + d] = u02[1];
+                    o1[d] = u13[0]; o1[2 + d] = u13[1];
+                }
+                const int c0 = cg * COUT_T + nt * 32 + 16 * h;
+                if (valid && c0 < p.cout_store) {
+                    u32x4 *dst = reinterpret_cast<u32x4 *>(p.out16 + pix * p.out16_cs + p.out16_coff + c0);
+                    dst[0] = o0;
+                    dst[1] = o1;
+                }
             }
             if (p.out_f32 && valid) {
                 const size_t plane = (size_t)p.Hob * p.Wob;

@@ -44,9 +44,11 @@ hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const floa
                         double det_thr, double tag_thr, float *joints, int32_t *num_people, float *ws_tags, int32_t *flags,
                         hipStream_t s);
 // per image: quarter-pixel adjust (optional) and person scores
-hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, float *joints, const int32_t *num_people, float *scores,
-                                hipStream_t s);
-// refine: mean tag per person, then full-map argmax for every missing joint
+// adjust + person scores + (refine != 0) the mean tag of every person and the lists of its missing joints
+hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, int refine, float *joints, const int32_t *num_people, float *scores,
+                                float *ws_prev, int32_t *ws_jobs, hipStream_t s);
+// refine: tag bounds + cleared work lists (in front of launch_adjust_scores), then the full-map argmax for every missing joint
+hipError_t launch_refine_prepare(const DecodeSrc &src, int M, unsigned long long *ws_best, int32_t *ws_jobs, float *tagb, hipStream_t s);
 hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev,
                          unsigned long long *ws_best, int32_t *ws_jobs, const float *cellmax, float *tagb, hipStream_t s);
 // dst (+)= weight * bilinear(src -> HxW), torch CPU arithmetic, any ratio (multi-scale heatmap aggregation)

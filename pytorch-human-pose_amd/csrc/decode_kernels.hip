@@ -586,6 +586,35 @@ __device__ void np_mean_rows(const float *rows, int n, int E, float *out)
     }
 }
 
+// np.mean of up to 18 float32 values (E == 1: the tag list of one group, K + 1 <= 18 slots): the same additions in the same order
+// as np_sum_f32 -- sequential below 8 values, 8 partial sums + pairwise tree + sequential tail from 8 on -- on values that are all
+// loaded before the first use (the rolled loop waits for LDS once per value).
+__device__ __forceinline__ float np_mean18(const float *rows, int n)
+{
+    float v[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) v[i] = rows[i < n ? i : 0];
+    float res;
+    if (n < 8) {
+        res = v[0];
+#pragma unroll
+        for (int i = 1; i < 7; ++i) res = i < n ? res + v[i] : res;
+    } else {
+        float r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = n >= 16 ? v[q] + v[8 + q] : v[q];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        if (n >= 16) {
+            res = 16 < n ? res + v[16] : res;
+            res = 17 < n ? res + v[17] : res;
+        } else {
+#pragma unroll
+            for (int i = 8; i < 16; ++i) res = i < n ? res + v[i] : res;
+        }
+    }
+    return __fdiv_rn(res, (float)n);
+}
+
 // ------------------------------------------------------------------ match_by_tag
 // grouping.py:85-145 with munkres 1.1.4 (munkres.py:114-340) restated wave-parallel: one wave per image.  The cost matrix
 // (float64) is built in LDS, then column j lives in the registers of lane j; the zero pattern of row i is a 64-bit mask on
@@ -612,28 +641,69 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int l)
     return ((u64)hi << 32) | lo;
 }
 
-// -> 0 and `star` = the starred column of row `lane` (-1: none), or 1 if the iteration guard ran out
-// NMAX >= n: the length of the unrolled column loops (the column of lane j lives in NMAX registers)
+// Cost matrix of one joint + munkres.  -> 0 and `star` = the starred column of row `lane` (-1: none), or 1 if the iteration guard
+// ran out.  NMAX >= n = max(na, ng): the length of the unrolled loops (row `lane` / column `lane` live in NMAX registers).
+// Lane a builds ROW a in registers: cost(a, g) = rint(|tag_a - mean_g|) * 100 - score_a for the ng groups (the unrounded distance
+// goes to S.saved for the acceptance test), 1e10 for the columns the reference pads with when candidates outnumber groups
+// (grouping.py:126-128), zeros for the rows munkres pads with; step 1 (row minimum) runs on those registers, the reduced row goes to
+// LDS once and comes back transposed.
 template <int NMAX>
-__device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
+__device__ int munkres_wave_n(MatchShared &S, int na, int ng, int E, int lane, int &star)
 {
-    // step 1: subtract the row minimum (lane = row, on the LDS copy)
-    if (lane < n) {
-        double mn = S.Cm[lane * MLD];
-        for (int j = 1; j < n; ++j) { const double c = S.Cm[lane * MLD + j]; if (c < mn) mn = c; }
-        for (int j = 0; j < n; ++j) S.Cm[lane * MLD + j] -= mn;
+    const int n = na > ng ? na : ng;
+    {
+        double rowv[NMAX];
+        const bool cand = lane < na;
+        const double sc = cand ? S.cj[lane * 3 + 2] : 0.0;
+        float ct[HH_MAX_EMB];
+#pragma unroll
+        for (int e = 0; e < HH_MAX_EMB; ++e) ct[e] = (cand && e < E) ? S.ctag[lane * HH_MAX_EMB + e] : 0.f;
+#pragma unroll
+        for (int g = 0; g < NMAX; ++g) {
+            double c = 0.0;  // munkres pad_matrix rows
+            if (g < n && cand) {
+                if (g < ng) {
+                    double ss = 0.0;
+#pragma unroll
+                    for (int e = 0; e < HH_MAX_EMB; ++e)
+                        if (e < E) {
+                            const double d = (double)ct[e] - (double)S.gmean[g * HH_MAX_EMB + e];
+                            ss = ss + d * d;
+                        }
+                    const double dist = __dsqrt_rn(ss);
+                    S.saved[lane * MLD + g] = dist;
+                    c = rint(dist) * 100.0 - sc;
+                } else {
+                    c = 1e10;  // grouping.py:126-128
+                }
+            }
+            rowv[g] = c;
+        }
+        // step 1: subtract the row minimum
+        double mn = rowv[0];
+#pragma unroll
+        for (int j = 1; j < NMAX; ++j) if (j < n && rowv[j] < mn) mn = rowv[j];
+        if (lane < n) {
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) if (j < n) S.Cm[lane * MLD + j] = rowv[j] - mn;
+        }
     }
     __syncthreads();
     double col[NMAX];  // column `lane`
     u64 myz = 0;                // zeros of row `lane`
+    {
+        const int cl = lane < n ? lane : 0;
 #pragma unroll
-    for (int i = 0; i < NMAX; ++i) {
-        col[i] = 1.0;
-        if (i < n) {
-            if (lane < n) col[i] = S.Cm[i * MLD + lane];
-            const u64 m = __ballot(lane < n && col[i] == 0.0);
-            if (lane == i) myz = m;
+        for (int i = 0; i < NMAX; ++i) {  // every read in flight before the first ballot needs one
+            const double v = S.Cm[(i < n ? i : 0) * MLD + cl];
+            col[i] = (i < n && lane < n) ? v : 1.0;
         }
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i)
+            if (i < n) {
+                const u64 m = __ballot(lane < n && col[i] == 0.0);
+                if (lane == i) myz = m;
+            }
     }
     int starcol = -1, primecol = -1;  // of row `lane`
     u64 ccm = 0, rcm = 0;             // covered columns / rows
@@ -721,12 +791,13 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
 }
 
 // most images hold far fewer than HH_MAX_PEOPLE candidates per joint: the short instantiations skip the masked-off iterations
-__device__ __forceinline__ int munkres_wave(MatchShared &S, int n, int lane, int &star)
+__device__ __forceinline__ int munkres_wave(MatchShared &S, int na, int ng, int E, int lane, int &star)
 {
-    if (n <= 8) return munkres_wave_n<8>(S, n, lane, star);
-    if (n <= 16) return munkres_wave_n<16>(S, n, lane, star);
-    if (n <= 24) return munkres_wave_n<24>(S, n, lane, star);
-    return munkres_wave_n<HH_MAX_PEOPLE>(S, n, lane, star);
+    const int n = na > ng ? na : ng;
+    if (n <= 8) return munkres_wave_n<8>(S, na, ng, E, lane, star);
+    if (n <= 16) return munkres_wave_n<16>(S, na, ng, E, lane, star);
+    if (n <= 24) return munkres_wave_n<24>(S, na, ng, E, lane, star);
+    return munkres_wave_n<HH_MAX_PEOPLE>(S, na, ng, E, lane, star);
 }
 
 __constant__ int c_joints_order[17] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 7, 8, 9, 10, 13, 14, 15, 16};  // grouping.py:63-65
@@ -777,31 +848,14 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
         int ng = 0;
         if (!first) {
             ng = G < M ? G : M;
-            if (lane < ng) np_mean_rows(GT + (size_t)lane * (K + 1) * E, S.gnt[lane], E, &S.gmean[lane * HH_MAX_EMB]);
-            __syncthreads();
-            const int n = na > ng ? na : ng;
-            for (int i = lane; i < n * n; i += 64) {
-                const int a = i / n, g = i % n;
-                double c = 0.0;  // munkres pad_matrix rows
-                if (a < na) {
-                    if (g < ng) {
-                        double ss = 0.0;
-                        for (int e = 0; e < E; ++e) {
-                            const double d = (double)S.ctag[a * HH_MAX_EMB + e] - (double)S.gmean[g * HH_MAX_EMB + e];
-                            ss = ss + d * d;
-                        }
-                        const double dist = __dsqrt_rn(ss);
-                        S.saved[a * MLD + g] = dist;
-                        c = rint(dist) * 100.0 - S.cj[a * 3 + 2];
-                    } else {
-                        c = 1e10;  // grouping.py:126-128
-                    }
-                }
-                S.Cm[a * MLD + g] = c;
+            if (lane < ng) {
+                const int nt = S.gnt[lane];
+                if (E == 1 && nt <= 18) S.gmean[lane * HH_MAX_EMB] = np_mean18(GT + (size_t)lane * (K + 1), nt);
+                else np_mean_rows(GT + (size_t)lane * (K + 1) * E, nt, E, &S.gmean[lane * HH_MAX_EMB]);
             }
             __syncthreads();
             int star = -1;
-            bad |= munkres_wave(S, n, lane, star);
+            bad |= munkres_wave(S, na, ng, E, lane, star);
             if (lane < na) S.assign[lane] = star;
             __syncthreads();
         }
@@ -845,8 +899,10 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
                 __syncthreads();
             }
         }
-        if (lane == 0) {  // candidates in row order
+        {   // candidates in row order; the loop is wave-uniform: the search for an existing key is one ballot over the groups' keys
+            // (lane q holds the key of group q) instead of a scan on one lane, lane 0 does the writes
             int Gc = S.G;
+            float gkreg = lane < Gc ? S.gkey[lane] : __builtin_nanf("");
             for (u64 sm = serial; sm; sm &= sm - 1) {
                 const int a = __builtin_ctzll(sm);
                 int t;
@@ -854,24 +910,27 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
                 if (!first && col >= 0 && col < ng && S.saved[a * MLD + col] < tag_thr) t = col;
                 else {
                     const float key = S.ctag[a * HH_MAX_EMB];
-                    t = -1;
-                    for (int q = 0; q < Gc; ++q) if (S.gkey[q] == key) { t = q; break; }
-                    if (t < 0) {
+                    const u64 hit = __ballot(lane < Gc && gkreg == key);
+                    if (hit) t = __builtin_ctzll(hit);  // (the first group with that key, as the scan in key order found it)
+                    else {
                         if (Gc >= M) continue;  // groups past max_num_people are never matched nor returned
                         t = Gc++;
-                        S.gkey[t] = key;
+                        if (lane == t) gkreg = key;
+                        if (lane == 0) S.gkey[t] = key;
                     }
-                    S.gnt[t] = 0;
+                    if (lane == 0) S.gnt[t] = 0;
                 }
-                float *jr = J + ((size_t)t * K + idx) * D;
-                jr[0] = (float)S.cj[a * 3 + 0]; jr[1] = (float)S.cj[a * 3 + 1]; jr[2] = (float)S.cj[a * 3 + 2];
-                for (int e = 0; e < E; ++e) {
-                    jr[3 + e] = S.ctag[a * HH_MAX_EMB + e];
-                    GT[((size_t)t * (K + 1) + S.gnt[t]) * E + e] = S.ctag[a * HH_MAX_EMB + e];
+                if (lane == 0) {
+                    float *jr = J + ((size_t)t * K + idx) * D;
+                    jr[0] = (float)S.cj[a * 3 + 0]; jr[1] = (float)S.cj[a * 3 + 1]; jr[2] = (float)S.cj[a * 3 + 2];
+                    for (int e = 0; e < E; ++e) {
+                        jr[3 + e] = S.ctag[a * HH_MAX_EMB + e];
+                        GT[((size_t)t * (K + 1) + S.gnt[t]) * E + e] = S.ctag[a * HH_MAX_EMB + e];
+                    }
+                    S.gnt[t] += 1;
                 }
-                S.gnt[t] += 1;
             }
-            S.G = Gc;
+            if (lane == 0) S.G = Gc;
         }
         __syncthreads();
     }
@@ -906,68 +965,74 @@ hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const floa
 
 // ------------------------------------------------------------------ adjust + person scores
 // grouping.py:172-191 and :276 (scores = joints[..., 2].mean(1), taken BEFORE refine)
-__global__ __launch_bounds__(256) void adjust_scores_kernel(const DecodeSrc src, int M, int adjust, float *__restrict__ joints,
-                                                            const int32_t *__restrict__ num_people, float *__restrict__ scores)
+__global__ __launch_bounds__(256) void adjust_scores_kernel(const DecodeSrc src, int M, int adjust, int refine, float *__restrict__ joints,
+                                                            const int32_t *__restrict__ num_people, float *__restrict__ scores,
+                                                            float *__restrict__ ws_prev, int32_t *__restrict__ ws_jobs)
 {
-    const int b = blockIdx.x, tid = threadIdx.x, K = src.K, D = 3 + src.E;
-    const int P = num_people[b];
+    // + the first step of refine (grouping.py:200-214: the mean tag of a person's detected joints, read at the adjusted
+    // coordinates' pixel) and the work lists of the arg-max pass: the tag of every (person, joint) is sampled by the thread that
+    // adjusts it -- P * K independent reads instead of one thread per person walking its joints one dependent read after the other
+    __shared__ float tl[HH_MAX_PEOPLE * 64 * HH_MAX_EMB];  // [p][k][e]; K <= 64
+    const int b = blockIdx.x, tid = threadIdx.x, K = src.K, E = src.E, D = 3 + E;
+    const int P = min(num_people[b], M);
     float *J = joints + (size_t)b * M * K * D;
-    if (adjust)
-        for (int i = tid; i < P * K; i += 256) {
-            float *j = J + (size_t)i * D;
-            const int k = i % K;
-            if (j[2] == 0.f) continue;
-            float x = j[0], y = j[1];
-            const int xi = (int)x, yi = (int)y;
+    for (int i = tid; i < P * K; i += 256) {
+        float *j = J + (size_t)i * D;
+        const int k = i % K;
+        if (j[2] == 0.f) continue;
+        float x = j[0], y = j[1];
+        const int xi = (int)x, yi = (int)y;
+        if (adjust) {
             const int xr = min(xi + 1, src.W - 1), xl = max(xi - 1, 0), yd = min(yi + 1, src.H - 1), yu = max(yi - 1, 0);
             if (heat_at(src, b, k, yi, xr) > heat_at(src, b, k, yi, xl)) x += 0.25f; else x -= 0.25f;
             if (heat_at(src, b, k, yd, xi) > heat_at(src, b, k, yu, xi)) y += 0.25f; else y -= 0.25f;
-            j[0] = x + 0.5f; j[1] = y + 0.5f;
+            x += 0.5f; y += 0.5f;
+            j[0] = x; j[1] = y;
         }
+        if (refine && j[2] > 0.f) {
+            const int xt = (int)x, yt = (int)y;  // grouping.py:206-207: the pixel of the (adjusted) coordinates
+            for (int e = 0; e < E; ++e) tl[i * E + e] = tag_at(src, b, k, yt, xt, e);
+        }
+    }
     __syncthreads();
     for (int p = tid; p < M; p += 256)
         scores[(size_t)b * M + p] = p < P ? __fdiv_rn(np_sum_f32(J + (size_t)p * K * D + 2, K, D), (float)K) : 0.f;
+    if (!refine || tid >= P) return;
+    {
+        const int p = tid;
+        const float *Jp = J + (size_t)p * K * D;
+        float *mine = tl + (size_t)p * K * E;  // compacted in place, in joint order (the write index never passes the read index)
+        int nt = 0;
+        for (int k = 0; k < K; ++k)
+            if (Jp[k * D + 2] > 0.f) {
+                for (int e = 0; e < E; ++e) mine[nt * E + e] = mine[k * E + e];
+                ++nt;
+            }
+        float *out = ws_prev + ((size_t)b * M + p) * (HH_MAX_EMB + 1);
+        out[HH_MAX_EMB] = (float)nt;
+        if (!nt) return;
+        np_mean_rows(mine, nt, E, out);
+        // work lists for the arg-max kernel: every joint of this person still missing, in 8 queues by map ((b*K + k) % 8).
+        // A queue is served by the workgroups of ONE XCD, so the several people that miss the same joint of an image scan that
+        // map's cell maxima / tag bounds out of the same L2 instead of fetching them once per XCD.
+        const int cap = gridDim.x * M * K;  // queue capacity = every (b, p, k)
+        for (int k = 0; k < K; ++k)
+            if (Jp[k * D + 2] == 0.f) {
+                const int qx = (b * K + k) & 7;
+                ws_jobs[8 + qx * cap + atomicAdd(ws_jobs + qx, 1)] = (b << 16) | (p << 8) | k;
+            }
+    }
 }
 
-hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, float *joints, const int32_t *num_people, float *scores,
-                                hipStream_t s)
+hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, int refine, float *joints, const int32_t *num_people, float *scores,
+                                float *ws_prev, int32_t *ws_jobs, hipStream_t s)
 {
-    hipLaunchKernelGGL(adjust_scores_kernel, dim3(src.B), dim3(256), 0, s, src, M, adjust, joints, num_people, scores);
+    hipLaunchKernelGGL(adjust_scores_kernel, dim3(src.B), dim3(256), 0, s, src, M, adjust, refine, joints, num_people, scores, ws_prev, ws_jobs);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ refine
-// grouping.py:193-250.  (1) per person: mean tag of its detected joints.
-__global__ __launch_bounds__(64) void refine_mean_kernel(const DecodeSrc src, int M, const float *__restrict__ joints,
-                                                         const int32_t *__restrict__ num_people, float *__restrict__ ws_prev,
-                                                         int32_t *__restrict__ ws_jobs)
-{
-    const int b = blockIdx.x, p = threadIdx.x, K = src.K, E = src.E, D = 3 + E;
-    if (p >= num_people[b] || p >= M) return;
-    const float *J = joints + ((size_t)b * M + p) * K * D;
-    float tl[64 * HH_MAX_EMB];
-    int nt = 0;
-    for (int k = 0; k < K; ++k)
-        if (J[k * D + 2] > 0.f) {
-            const int x = (int)J[k * D + 0], y = (int)J[k * D + 1];
-            for (int e = 0; e < E; ++e) tl[nt * E + e] = tag_at(src, b, k, y, x, e);
-            ++nt;
-        }
-    float *out = ws_prev + ((size_t)b * M + p) * (HH_MAX_EMB + 1);
-    out[HH_MAX_EMB] = (float)nt;
-    if (!nt) return;
-    np_mean_rows(tl, nt, E, out);
-    // work lists for the arg-max kernel: every joint of this person still missing, in 8 queues by map ((b*K + k) % 8).
-    // A queue is served by the workgroups of ONE XCD, so the several people that miss the same joint of an image scan that
-    // map's cell maxima / tag bounds out of the same L2 instead of fetching them once per XCD.
-    const int cap = gridDim.x * M * K;  // queue capacity = every (b, p, k)
-    for (int k = 0; k < K; ++k)
-        if (J[k * D + 2] == 0.f) {
-            const int qx = (b * K + k) & 7;
-            ws_jobs[8 + qx * cap + atomicAdd(ws_jobs + qx, 1)] = (b << 16) | (p << 8) | k;
-        }
-}
-
+// grouping.py:193-250.  (1) per person: the mean tag of its detected joints and the lists of its missing joints: adjust_scores_kernel.
 // (1b) per (b,k) quarter-res cell: [lo, hi] of the 3x3 tag taps (slack included) -- shared by every person
 // The launch also clears the work lists of the arg-max pass (ws_best: n_best entries, ws_jobs: the 8 queue counters), one entry
 // per thread of the grid: two fill launches less in front of refine_mean_kernel.
@@ -1214,8 +1279,9 @@ __global__ __launch_bounds__(64) void refine_apply_kernel(const DecodeSrc src, i
     }
 }
 
-hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev,
-                         unsigned long long *ws_best, int32_t *ws_jobs, const float *cellmax, float *tagb, hipStream_t s)
+// what the refine passes need from the input maps alone (tag bounds) + cleared work lists: in front of adjust_scores_kernel, which
+// fills the lists
+hipError_t launch_refine_prepare(const DecodeSrc &src, int M, unsigned long long *ws_best, int32_t *ws_jobs, float *tagb, hipStream_t s)
 {
     const int nx = ((((src.H >> 2) + 7) / 8) * (src.W >> 2) + 255) / 256;  // 8 = TBR
     if (src.mode == 0 && (size_t)nx * 256 >= (size_t)M) {  // (grid threads >= B * M * K entries)
@@ -1227,7 +1293,11 @@ hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32
         e = hipMemsetAsync(ws_jobs, 0, 32, s);  // the 8 queue counters
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(refine_mean_kernel, dim3(src.B), dim3(64), 0, s, src, M, joints, num_people, ws_prev, ws_jobs);
+    return hipGetLastError();
+}
+hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev,
+                         unsigned long long *ws_best, int32_t *ws_jobs, const float *cellmax, float *tagb, hipStream_t s)
+{
     hipLaunchKernelGGL(refine_argmax_kernel, dim3(2048), dim3(256), 0, s, src, M, ws_jobs, ws_prev, cellmax, tagb, ws_best);
     hipLaunchKernelGGL(refine_apply_kernel, dim3(M, src.B), dim3(64), 0, s, src, M, joints, num_people, ws_best);
     return hipGetLastError();

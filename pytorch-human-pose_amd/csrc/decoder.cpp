@@ -79,10 +79,11 @@ int hh_decoder::run(DecodeSrc &src, int adjust, int refine, float *joints, float
     HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, cellmax, skip ? thr_f : -INFINITY, s));
     last_exact = !skip;
     HH_CHECK_HIP(launch_topk_merge(src, M, nt, cand_key, cand_val, tags_k, coords_k, scores_k, s));
+    if (refine) HH_CHECK_HIP(launch_refine_prepare(src, M, ws_best, ws_jobs, tagb, s));
     HH_CHECK_HIP(launch_match(tags_k, coords_k, scores_k, src.B, K, M, src.E, det_thr, tag_thr, joints, num_people, ws_tags, flags_out ? flags_out : flags, s));
     flags_last = flags_out ? flags_out : flags;
     if (skip) HH_CHECK_HIP(launch_fallback_top1(src, M, flags_last, joints, s));
-    HH_CHECK_HIP(launch_adjust_scores(src, M, adjust, joints, num_people, scores, s));
+    HH_CHECK_HIP(launch_adjust_scores(src, M, adjust, refine, joints, num_people, scores, ws_prev, ws_jobs, s));
     if (refine) HH_CHECK_HIP(launch_refine(src, M, joints, num_people, ws_prev, ws_best, ws_jobs, cellmax, tagb, s));
     lastB = src.B; lastE = src.E;
     return 0;

@@ -31,6 +31,8 @@ PlanSwitches PlanSwitches::from_env()
     s.no_fusion_merge = on("HH_NO_FUSION_MERGE");
     s.poison_ws = on("HH_POISON_WS");
     s.poison_lds = on("HH_POISON_LDS");
+    s.fp8_trunk8 = is("HH_FP8_TRUNK", "e4m3");
+    s.fp8_heads8 = is("HH_FP8_HEADS", "e4m3");
     return s;
 }
 
@@ -500,9 +502,14 @@ struct Builder {
         }
 
         // heads (higher_hrnet.py:52,70-79): 1x1 conv with bias -> fp32 NCHW result AND bf16 copy into CAT
+        // fp8 handles run the three heads (this 1x1, the transposed conv, the final 1x1: 1.3 % of the FLOPs) on the bf16 kernels over
+        // the bf16 representations: their e4m3 rounding lands on the outputs undamped (tools/probes/fp8_emulate.py: 7.8 -> 6.4 %
+        // rms on the tags of W48).  HH_FP8_HEADS=e4m3 keeps them on the e4m3 kernels.
+        const bool hi_heads = n.dtype == 2 && !n.sw.fp8_heads8;
         {
             Op &o = conv(L("init_heatmaps_head", "", C, 2 * K, 1, 1, "init_heatmaps_head.bias"), CAT, CAT, 0);
             o.out_coff = C; o.cout_store = catC - C; o.f32_out = 1;
+            o.hi = hi_heads; n.layers[o.layer].hi = hi_heads;
         }
         // DeconvHeatmapsHead (higher_hrnet.py:7-44): ConvTranspose2d(k4,s2,p1) = 4 phase-wise 2x2 convs
         const std::string dp = "deconv_layers.0";
@@ -512,12 +519,19 @@ struct Builder {
             n.layers[l].transposed = true; n.layers[l].py = -1; n.layers[l].px = -1;
             Op &o = conv(l, CAT, DF, 1);
             o.scatter = 1;
+            o.hi = hi_heads; n.layers[l].hi = hi_heads;
+        }
+        if (hi_heads) {  // the residual blocks' first conv reads DF as e4m3
+            Op q;
+            q.kind = OP_QUANT; q.out = DF; q.lane = lane;
+            n.ops.push_back(q);
         }
         basic_blocks(dp + ".resid_blocks", C, DF, DM);
         tap("deconv#0", DF, C);
         {
             Op &o = conv(L(dp + ".final_layer", "", C, K, 1, 1, dp + ".final_layer.bias"), DF, -1, 0);
             o.f32_out = 2;
+            o.hi = hi_heads; n.layers[o.layer].hi = hi_heads;
         }
     }
 };
@@ -528,7 +542,33 @@ int hh_net::build()
     Builder b(*this);
     b.register_params();
     b.build_plan();
+    if (dtype == 2) assign_fp8_formats();
     return 0;
+}
+
+// fp8 plans: a tensor is kept as e4m3 (+ one scale) where a conv reads it as an MFMA operand, and as bf16 where it is read back
+// as a residual, by a fusion sum or by an op that runs on the bf16 kernels -- so the residual trunk (block in / out, fusion
+// outputs) is written in BOTH forms by its producer and never goes through e4m3 on its own way forward: every block then adds
+// the error of its two convs only, instead of also re-rounding the whole trunk to 3 mantissa bits (16-19 % -> 6-9 % rms at the
+// outputs of the seeded nets, tools/probes/fp8_emulate.py).  HH_FP8_TRUNK=e4m3: everything e4m3 (the round-2 plan).
+void hh_net::assign_fp8_formats()
+{
+    for (auto &t : tensors) { t.f8 = sw.fp8_trunk8; t.b16 = false; }
+    auto need8 = [&](int t) { if (t >= 0) tensors[t].f8 = true; };
+    auto need16 = [&](int t) { if (t >= 0) { if (sw.fp8_trunk8) tensors[t].f8 = true; else tensors[t].b16 = true; } };
+    for (const Op &op : ops) {
+        switch (op.kind) {
+        case OP_STEM: need8(op.out); break;  // stem_conv.hip writes e4m3 only
+        case OP_CONV:
+            if (op.hi) { if (op.in >= 0) tensors[op.in].b16 = true; if (op.out >= 0) tensors[op.out].b16 = true; }
+            else { need8(op.in); need16(op.res); }
+            break;
+        case OP_BB: need8(op.in); need16(op.in); break;
+        case OP_UPADD: need16(op.in); for (int j = 0; j < op.nup; ++j) need16(op.up[j]); break;
+        case OP_QUANT: tensors[op.out].f8 = true; tensors[op.out].b16 = true; break;
+        default: break;
+        }
+    }
 }
 
 // Kernel-order weight image: [cout_group][cin_chunk][tap][KC/8][COUT_T][8] bf16, BN scale folded in, zero padded.
@@ -617,7 +657,7 @@ int hh_net::finalize()
             HH_CHECK_HIP(hipMemcpy(l.d_bias, shift.data(), 64 * 4, hipMemcpyHostToDevice));
             continue;
         }
-        if (dtype == 2) continue;  // e4m3 weights: finalize_fp8() below
+        if (dtype == 2 && !l.hi) continue;  // e4m3 weights: finalize_fp8() below
         const int cin_pad0 = round_up(l.cin, 16), coutp = round_up(l.cout, 32);
         if (l.bb128) { l.KC = 16; l.NT = 4; }  // basicblock_fused_c128.hip: [chunk of 16 cin][tap][2][128 couts][8]
         else if (l.stem2) { l.KC = 64; l.NT = 2; }  // stem_fused.hip: [tap][8][64 couts][8]
@@ -710,7 +750,8 @@ void hh_net::release_workspace()
 {
     for (void *p : allocs) hipFree(p);
     allocs.clear();
-    for (auto &t : tensors) t.ptr = nullptr;
+    for (auto &t : tensors) { t.ptr = nullptr; t.ptr16 = nullptr; }
+    ws_ready = false;
     for (auto &t : taps) t.copy = nullptr;
     for (auto &g : graphs) hipGraphExecDestroy(g.exec);
     graphs.clear();
@@ -721,7 +762,7 @@ void hh_net::release_workspace()
 int hh_net::reserve(int B, int H, int W)
 {
     if (H % 32 || W % 32 || B <= 0) { hh_set_error("hh_reserve: H and W must be positive multiples of 32"); return 1; }
-    const bool have = tensors[0].ptr && (!taps_enabled || taps.empty() || taps[0].copy);
+    const bool have = ws_ready && (!taps_enabled || taps.empty() || taps[0].copy);
     if (have && B <= rB && H <= rH && W <= rW) return 0;
     const int nB = std::max(B, rB), nH = std::max(H, rH), nW = std::max(W, rW);
     release_workspace();
@@ -732,18 +773,28 @@ int hh_net::reserve(int B, int H, int W)
         return 0;
     };
     for (auto &t : tensors) {
-        const size_t bytes = (size_t)nB * (nH >> t.shift) * (nW >> t.shift) * t.C * elem();
-        if (alloc(bytes, (void **)&t.ptr)) return 1;
+        const size_t n = (size_t)nB * (nH >> t.shift) * (nW >> t.shift) * t.C;
         // HH_POISON_WS=1 (tests): recycled device memory is not zero -- fill the workspace with NaN patterns so that a kernel
         // that reads what no kernel wrote shows up in the outputs instead of depending on what the allocator hands out
-        if (sw.poison_ws) HH_CHECK_HIP(hipMemset(t.ptr, 0xFF, bytes));
-        if (t.zero_init) HH_CHECK_HIP(hipMemset(t.ptr, 0, bytes));
+        if (dtype != 2 || t.f8) {
+            const size_t bytes = n * elem();
+            if (alloc(bytes, (void **)&t.ptr)) return 1;
+            if (sw.poison_ws) HH_CHECK_HIP(hipMemset(t.ptr, 0xFF, bytes));
+            if (t.zero_init) HH_CHECK_HIP(hipMemset(t.ptr, 0, bytes));
+        }
+        if (dtype == 2 && t.b16) {
+            if (alloc(n * 2, (void **)&t.ptr16)) return 1;
+            if (sw.poison_ws) HH_CHECK_HIP(hipMemset(t.ptr16, 0xFF, n * 2));
+            if (t.zero_init) HH_CHECK_HIP(hipMemset(t.ptr16, 0, n * 2));
+        }
     }
     if (taps_enabled)
         for (auto &t : taps) {
             const TensorDesc &d = tensors[t.tensor];
-            if (alloc((size_t)nB * (nH >> d.shift) * (nW >> d.shift) * d.C * elem(), (void **)&t.copy)) return 1;
+            t.is16 = dtype == 2 && d.b16;
+            if (alloc((size_t)nB * (nH >> d.shift) * (nW >> d.shift) * d.C * (t.is16 ? 2 : elem()), (void **)&t.copy)) return 1;
         }
+    ws_ready = true;
     rB = nB; rH = nH; rW = nW;
     return 0;
 }
@@ -943,7 +994,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             if (!taps_enabled) break;
             const TapInfo &t = taps[op.tap];
             const TensorDesc &d = tensors[t.tensor];
-            HH_CHECK_HIP(hipMemcpyAsync(t.copy, d.ptr, (size_t)B * (H >> d.shift) * (W >> d.shift) * d.C * elem(),
+            HH_CHECK_HIP(hipMemcpyAsync(t.copy, t.is16 ? d.ptr16 : d.ptr, (size_t)B * (H >> d.shift) * (W >> d.shift) * d.C * (t.is16 ? 2 : elem()),
                                         hipMemcpyDeviceToDevice, s));
             break;
         }
@@ -1045,8 +1096,11 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             else HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
             break;
         }
+        case OP_QUANT:
+            if (enqueue_fp8_quant(op, B, H, W, s)) return 1;
+            break;
         case OP_CONV: {
-            if (dtype == 2) {
+            if (dtype == 2 && !op.hi) {
                 ProfRecord *pr = nullptr;
                 if (prof_enabled) {
                     if (prof_used == prof.size()) {
@@ -1066,7 +1120,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             const TensorDesc &ti = tensors[op.in];
             ConvParams p{};
             p.Hin = H >> ti.shift; p.Win = W >> ti.shift;
-            p.in = ti.ptr; p.in_cs = ti.C; p.in_coff = op.in_coff;
+            p.in = dtype == 2 ? ti.ptr16 : ti.ptr; p.in_cs = ti.C; p.in_coff = op.in_coff;  // (fp8 handle, op.hi: the bf16 representations)
             p.w = l.d_w; p.bias = l.d_bias;
             p.Ho = l.stride == 2 ? p.Hin / 2 : p.Hin;
             p.Wo = l.stride == 2 ? p.Win / 2 : p.Win;
@@ -1080,11 +1134,11 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             p.Hob = p.Ho * p.osy; p.Wob = p.Wo * p.osx;
             if (op.out >= 0) {
                 const TensorDesc &to = tensors[op.out];
-                p.out = to.ptr; p.out_cs = to.C; p.out_coff = op.out_coff;
+                p.out = dtype == 2 ? to.ptr16 : to.ptr; p.out_cs = to.C; p.out_coff = op.out_coff;
             }
             if (op.res >= 0) {
                 const TensorDesc &tr = tensors[op.res];
-                p.res = tr.ptr; p.res_cs = tr.C; p.res_coff = op.res_coff;
+                p.res = dtype == 2 ? tr.ptr16 : tr.ptr; p.res_cs = tr.C; p.res_coff = op.res_coff;
             }
             p.out_f32 = op.f32_out == 1 ? o1 : op.f32_out == 2 ? o2 : nullptr;
             if (op.in2 >= 0) {  // conv over the concatenated channels of two or three tensors of one shape and pixel stride
@@ -1148,7 +1202,7 @@ int hh_net::forward(const float *images, int B, int H, int W, float *o1, float *
 {
     if (!finalized) { hh_set_error("hh_forward: call hh_finalize first"); return 1; }
     if (dtype == 2 && !calibrated) { hh_set_error("hh_forward: fp8 handle without activation scales, call hh_calibrate first"); return 1; }
-    if (B > rB || H > rH || W > rW || !tensors[0].ptr || (taps_enabled && !taps.empty() && !taps[0].copy))
+    if (B > rB || H > rH || W > rW || !ws_ready || (taps_enabled && !taps.empty() && !taps[0].copy))
         if (reserve(B, H, W)) return 1;
     lastB = B; lastH = H; lastW = W;
     // hipGraph capture of the multi-stream fork/join segfaults inside the ROCm 7.2 runtime on this plan, so the
@@ -1230,6 +1284,7 @@ int hh_net::check_plan(std::string *why) const
         case OP_BB: rd = {op.in}; wr = {op.out}; break;
         case OP_JUNC: rd = {op.in, op.in2, op.res, op.in3}; wr = {op.out, op.out2}; break;
         case OP_STEM: wr = {op.out}; break;
+        case OP_QUANT: rd = {op.out}; wr = {op.out}; break;
         case OP_TAP: continue;  // taps only run with the lanes switched off (enqueue: multi = ... && !taps_enabled)
         case OP_AVGPOOL: rd = {op.in}; break;
         default: break;
@@ -1323,7 +1378,7 @@ int hh_tap_read_impl(hh_net *n, int index, float *host)
     const TensorDesc &d = n->tensors[t.tensor];
     const int B = n->lastB, h = n->lastH >> d.shift, w = n->lastW >> d.shift;
     HH_CHECK_HIP(hipDeviceSynchronize());
-    if (n->dtype == 2) {  // e4m3 bytes * the tensor's scale at the tap
+    if (n->dtype == 2 && !t.is16) {  // e4m3 bytes * the tensor's scale at the tap
         std::vector<unsigned char> q((size_t)B * h * w * d.C);
         HH_CHECK_HIP(hipMemcpy(q.data(), t.copy, q.size(), hipMemcpyDeviceToHost));
         for (int b = 0; b < B; ++b)

@@ -39,6 +39,7 @@ struct ConvLayer {
     bool stem2 = false; // second stem conv inside stem_fused.hip: packed [tap][cin/8][64 couts][8]
     bool stem = false;  // first conv of the net: packed for stem_conv.hip (K = 27 taps padded to 32)
     bool bb128 = false; // conv of a fused 128-channel BasicBlock: packed with 16-channel chunks over all 128 couts
+    bool hi = false;    // fp8 handle: this layer runs on the bf16 kernels (the heads), packed like a bf16 handle's
     int py = 0, px = 0;  // phase of the transposed conv this entry implements (-1: all four, packed back to back)
     size_t phase_stride = 0;
     // chosen at finalize
@@ -54,11 +55,16 @@ struct ConvLayer {
 struct TensorDesc {
     int C = 0, shift = 0;  // spatial dims = (H >> shift, W >> shift)
     bf16_raw *ptr = nullptr;  // bf16 elements, or e4m3 bytes on the fp8 path (C bytes per pixel)
+    // fp8 handles keep up to TWO representations of a tensor: e4m3 * scale in `ptr` (f8: some conv reads it as an MFMA operand) and
+    // bf16 in `ptr16` (b16: it is read back as a residual / by a fusion sum / by a head that runs on the bf16 kernels) -- the
+    // residual trunk is never re-quantised to 3 mantissa bits (engine.cpp assign_fp8_formats)
+    bool f8 = true, b16 = false;
+    bf16_raw *ptr16 = nullptr;
     bool zero_init = false;
     bool shared_scale = false;  // fp8: written in channel slices by several ops (torch.cat buffer): one scale for all of them
 };
 
-enum OpKind { OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC, OP_STEM, OP_MARK, OP_WAITL };
+enum OpKind { OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC, OP_STEM, OP_MARK, OP_WAITL, OP_QUANT };
 
 struct Op {
     OpKind kind = OP_CONV;
@@ -77,6 +83,7 @@ struct Op {
     int up[3] = {-1, -1, -1}, up_shift[3] = {0, 0, 0}, nup = 0;
     int C = 0;  // UPADD channel count / TAP channel count
     int tap = -1;
+    bool hi = false;  // fp8 handle: OP_CONV on the bf16 kernels over the tensors' bf16 representations; OP_QUANT: tensor `out`'s bf16 -> e4m3
     int lane = 0;     // execution lane (HIP stream): resolution branches / fusion outputs run concurrently
     int nlanes = 0;   // OP_JOIN: all-to-all barrier over lanes [0, nlanes)
     int dep_from = 0; // OP_DEP: `lane` waits for everything enqueued so far on lane dep_from; OP_WAITL: `lane` waits for lane dep_from's
@@ -92,6 +99,7 @@ struct TapInfo {
     int tensor, coff, C;
     bf16_raw *copy = nullptr;
     float scale = 1.f;  // fp8: scale of the tensor at the tap's position in the plan
+    bool is16 = false;  // fp8: the copy holds the tensor's bf16 representation
 };
 
 struct ProfRecord {
@@ -122,6 +130,8 @@ struct PlanSwitches {
     bool no_fusion_merge = false;  // HH_NO_FUSION_MERGE=1: one launch per summed stride-2 conv of a fusion layer
     bool poison_ws = false;        // HH_POISON_WS=1 (tests): workspace filled with NaN patterns at allocation
     bool poison_lds = false;       // HH_POISON_LDS=1 (tests): every CU's LDS filled with NaN patterns in front of every launch
+    bool fp8_trunk8 = false;       // HH_FP8_TRUNK=e4m3: fp8 handles re-quantise the residual trunk to e4m3 in every block (the round-2 plan)
+    bool fp8_heads8 = false;       // HH_FP8_HEADS=e4m3: the two 1x1 heads and the transposed conv of an fp8 handle on the e4m3 kernels too
     static PlanSwitches from_env();
 };
 
@@ -143,6 +153,7 @@ struct hh_net {
     int rB = 0, rH = 0, rW = 0;  // reserved shape
     int lastB = 0, lastH = 0, lastW = 0;
     int64_t ws_bytes = 0;
+    bool ws_ready = false;  // reserve() has allocated the workspace for (rB, rH, rW)
     std::vector<void *> allocs;
     std::vector<GraphEntry> graphs;
     // live per-launch timing (bench.py roofline): HIP events on the launch stream around every conv
@@ -181,6 +192,8 @@ struct hh_net {
     int resolve_scales();  // amax -> per-op scales (plan order), d_mult of every layer
     int enqueue_fp8_conv(const Op &op, int B, int H, int W, float *o1, float *o2, hipStream_t s, ProfRecord *pr);
     int enqueue_fp8_upadd(const Op &op, int B, int H, int W, hipStream_t s);
+    int enqueue_fp8_quant(const Op &op, int B, int H, int W, hipStream_t s);
+    void assign_fp8_formats();  // which representations (e4m3 / bf16) every tensor of an fp8 plan needs, from its readers
     int enqueue_fp8_bb(const Op &op, int B, int H, int W, hipStream_t s, ProfRecord *pr);
     void release_workspace();
     ~hh_net();

@@ -93,7 +93,7 @@ int hh_net::finalize_fp8()
     HH_CHECK_HIP(conv_fp8_init());
     auto get = [&](const std::string &name) -> const std::vector<float> & { return params[param_index.at(name)].data; };
     for (auto &l : layers) {
-        if (l.stem) continue;  // packed by the common path (bf16 operands, e4m3 output)
+        if (l.stem || l.hi) continue;  // packed by the common path (bf16 operands)
         hh_fp8_family_pick(l.cin, l.cout, &l.KC, &l.NT);
         if (hh_fp8_pick_config(l.ks, l.stride, l.KC, l.NT, 32) < 0) { hh_set_error("no fp8 kernel for conv " + l.conv); return 1; }
         l.cin_pad = round_up(l.cin, l.KC);
@@ -176,6 +176,7 @@ int hh_net::resolve_scales()
             cur[op.out] = op.s_out;
             break;
         case OP_CONV: {
+            if (op.hi) break;  // bf16 kernels on bf16 representations: no scales
             op.s_in = cur[op.in];
             if (op.res >= 0) op.s_res = cur[op.res];
             if (op.out >= 0) {
@@ -200,6 +201,10 @@ int hh_net::resolve_scales()
             HH_CHECK_HIP(hipMemcpy(l2.d_mult, m2.data(), m2.size() * 4, hipMemcpyHostToDevice));
             break;
         }
+        case OP_QUANT:
+            op.s_out = scale_of(amax[i]);
+            cur[op.out] = op.s_out;
+            break;
         case OP_UPADD:
             op.s_in = cur[op.in];
             for (int j = 0; j < op.nup; ++j) op.s_up[j] = cur[op.up[j]];
@@ -227,7 +232,11 @@ int hh_net::calibrate(const float *images, int B, int H, int W, int rounds, hipS
     if (dtype != 2) { hh_set_error("hh_calibrate: not an fp8 handle"); return 1; }
     if (!finalized) { hh_set_error("hh_calibrate: call hh_finalize first"); return 1; }
     if (reserve(B, H, W)) return 1;
-    float *o1 = nullptr, *o2 = nullptr;
+    struct Outs {  // the forward's fp32 outputs are not wanted here: scratch, freed on every way out
+        float *o1 = nullptr, *o2 = nullptr;
+        ~Outs() { if (o1) hipFree(o1); if (o2) hipFree(o2); }
+    } outs;
+    float *&o1 = outs.o1, *&o2 = outs.o2;
     HH_CHECK_HIP(hipMalloc((void **)&o1, (size_t)B * 2 * K * (H / 4) * (W / 4) * 4));
     HH_CHECK_HIP(hipMalloc((void **)&o2, (size_t)B * K * (H / 2) * (W / 2) * 4));
     int rc = 0;
@@ -248,8 +257,6 @@ int hh_net::calibrate(const float *images, int B, int H, int W, int rounds, hipS
         }
         rc = resolve_scales();
     }
-    hipFree(o1);
-    hipFree(o2);
     if (!rc) calibrated = true;
     return rc;
 }
@@ -272,14 +279,15 @@ int hh_net::enqueue_fp8_conv(const Op &op, int B, int H, int W, float *o1, float
         if (l.py < 0) { p.nphase = 4; p.phase_stride = l.phase_stride; }
     }
     p.Hob = p.Ho * p.osy; p.Wob = p.Wo * p.osx;
-    if (op.out >= 0) {
+    if (op.out >= 0) {  // the representations the tensor's readers need (assign_fp8_formats)
         const TensorDesc &to = tensors[op.out];
-        p.out = (unsigned char *)to.ptr; p.out_cs = to.C; p.out_coff = op.out_coff;
-        p.out_inv_scale = 1.f / op.s_out;
+        if (to.f8) { p.out = (unsigned char *)to.ptr; p.out_cs = to.C; p.out_coff = op.out_coff; p.out_inv_scale = 1.f / op.s_out; }
+        if (to.b16) { p.out16 = to.ptr16; p.out16_cs = to.C; p.out16_coff = op.out_coff; }
     }
     if (op.res >= 0) {
         const TensorDesc &tr = tensors[op.res];
-        p.res = (const unsigned char *)tr.ptr; p.res_cs = tr.C; p.res_coff = op.res_coff; p.res_scale = op.s_res;
+        if (tr.b16) { p.res16 = tr.ptr16; p.res16_cs = tr.C; p.res16_coff = op.res_coff; }
+        else { p.res = (const unsigned char *)tr.ptr; p.res_cs = tr.C; p.res_coff = op.res_coff; p.res_scale = op.s_res; }
     }
     p.out_f32 = op.f32_out == 1 ? o1 : op.f32_out == 2 ? o2 : nullptr;
     p.cin = l.cin_pad;
@@ -297,7 +305,8 @@ int hh_net::enqueue_fp8_conv(const Op &op, int B, int H, int W, float *o1, float
         pr->cfg = 1000 + cfg;
         pr->flops = 2.0 * B * p.Ho * p.Wo * (double)l.cin * l.cout * l.ks * l.ks * (p.nphase > 1 ? 4 : 1);
         const double opix = (double)B * p.Ho * p.Wo * (p.nphase > 1 ? 4 : 1);
-        pr->bytes = 1.0 * B * p.Hin * p.Win * l.cin + (p.out ? opix * l.cout : 0.0) + (p.res ? opix * l.cout : 0.0) +
+        pr->bytes = 1.0 * B * p.Hin * p.Win * l.cin + (p.out ? opix * l.cout : 0.0) + (p.out16 ? 2.0 * opix * l.cout : 0.0) +
+                    (p.res ? opix * l.cout : 0.0) + (p.res16 ? 2.0 * opix * l.cout : 0.0) +
                     (p.out_f32 ? 4.0 * opix * l.cout : 0.0) + 1.0 * l.cin * l.cout * l.ks * l.ks * (p.nphase > 1 ? 4 : 1);
         hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};
     }
@@ -309,13 +318,17 @@ int hh_net::enqueue_fp8_upadd(const Op &op, int B, int H, int W, hipStream_t s)
 {
     UpAddFp8Params p{};
     const TensorDesc &b = tensors[op.in], &o = tensors[op.out];
-    p.base = (const unsigned char *)b.ptr; p.base_cs = b.C; p.base_scale = op.s_in;
+    if (b.b16) { p.base16 = b.ptr16; p.base16_cs = b.C; }
+    else { p.base = (const unsigned char *)b.ptr; p.base_cs = b.C; p.base_scale = op.s_in; }
     p.nup = op.nup;
     for (int j = 0; j < op.nup; ++j) {
-        p.up[j] = (const unsigned char *)tensors[op.up[j]].ptr; p.up_cs[j] = tensors[op.up[j]].C; p.up_shift[j] = op.up_shift[j];
-        p.up_scale[j] = op.s_up[j];
+        const TensorDesc &u = tensors[op.up[j]];
+        p.up_shift[j] = op.up_shift[j];
+        if (u.b16) { p.up16[j] = u.ptr16; p.up16_cs[j] = u.C; }
+        else { p.up[j] = (const unsigned char *)u.ptr; p.up_cs[j] = u.C; p.up_scale[j] = op.s_up[j]; }
     }
-    p.out = (unsigned char *)o.ptr; p.out_cs = o.C; p.out_inv_scale = 1.f / op.s_out;
+    if (o.f8) { p.out = (unsigned char *)o.ptr; p.out_cs = o.C; p.out_inv_scale = 1.f / op.s_out; }
+    if (o.b16) { p.out16 = o.ptr16; p.out16_cs = o.C; }
     p.B = B; p.H = H >> b.shift; p.W = W >> b.shift; p.C = round_up(op.C, 16); p.relu = op.relu;
     if (calibrating) p.absmax = d_amax + (&op - ops.data());
     HH_CHECK_HIP(launch_upadd_fp8(p, s));
@@ -331,15 +344,27 @@ int hh_net::enqueue_fp8_bb(const Op &op, int B, int H, int W, hipStream_t s, Pro
     p.w1 = (const unsigned char *)l1.d_w; p.w2 = (const unsigned char *)l2.d_w;
     p.mult1 = l1.d_mult; p.bias1 = l1.d_bias; p.mult2 = l2.d_mult; p.bias2 = l2.d_bias;
     p.mid_inv_scale = 1.f / op.s_mid; p.res_scale = op.s_in; p.out_inv_scale = 1.f / op.s_out;
+    if (ti.b16) { p.res16 = ti.ptr16; p.res16_cs = ti.C; }
+    if (to.b16) { p.out16 = to.ptr16; p.out16_cs = to.C; }
     p.B = B; p.H = H >> ti.shift; p.W = W >> ti.shift;
     if (calibrating) { p.amax_out = d_amax + (&op - ops.data()); p.amax_mid = d_amax + ops.size() + (&op - ops.data()); }
     if (pr) {
         const double Cb = l1.cout;
         pr->cfg = HH_CFG_BB_FP8;
         pr->flops = 2.0 * 2.0 * B * p.H * p.W * Cb * Cb * 9.0;
-        pr->bytes = 2.0 * B * p.H * p.W * Cb + 2.0 * 9 * Cb * Cb;
+        pr->bytes = (2.0 + (p.res16 ? 2.0 : 0.0) + (p.out16 ? 2.0 : 0.0)) * B * p.H * p.W * Cb + 2.0 * 9 * Cb * Cb;
         hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};
     }
     HH_CHECK_HIP(bb_fp8_launch(l1.cout, p, num_cus, s));
+    return 0;
+}
+
+// OP_QUANT: the e4m3 representation of a tensor from its bf16 one (a bf16-kernel op wrote it, an fp8 conv reads it)
+int hh_net::enqueue_fp8_quant(const Op &op, int B, int H, int W, hipStream_t s)
+{
+    const TensorDesc &t = tensors[op.out];
+    const size_t npix = (size_t)B * (H >> t.shift) * (W >> t.shift);
+    HH_CHECK_HIP(launch_quant_fp8(t.ptr16, t.C, (unsigned char *)t.ptr, t.C, npix, t.C, 1.f / op.s_out,
+                                  calibrating ? d_amax + (&op - ops.data()) : nullptr, s));
     return 0;
 }

@@ -85,9 +85,13 @@ struct Fp8ConvParams {
     const unsigned char *res; // optional residual (e4m3), same pixel grid as `out`
     int res_cs, res_coff;
     float res_scale;
+    const bf16_raw *res16;    // optional residual in bf16 (real values, no scale): the residual TRUNK of an fp8 net stays bf16
+    int res16_cs, res16_coff; //   (elements); takes precedence over `res`
     unsigned char *out;       // optional e4m3 NHWC output
     int out_cs, out_coff;
     float out_inv_scale;      // 1 / s_out
+    bf16_raw *out16;          // optional bf16 NHWC output of the same values (the trunk's second representation: read back as a
+    int out16_cs, out16_coff; //   residual / by the fusion sums; the e4m3 one feeds the next conv's MFMA); elements
     float *out_f32;           // optional fp32 NCHW output [B, cout_real, Hob, Wob]
     int Hob, Wob;
     int osy, ooy, osx, oox;
@@ -126,6 +130,9 @@ struct Fp8BBParams {
     const unsigned char *w1, *w2;
     const float *mult1, *bias1, *mult2, *bias2;  // [64]: s_in * s_w1[co], shift1, s_mid * s_w2[co], shift2 (0 for padding couts)
     float mid_inv_scale, res_scale, out_inv_scale;
+    const bf16_raw *res16; int res16_cs;  // optional: the block input in bf16 (same pixels as `in`): residual read from it instead of
+                                          // from the e4m3 patch
+    bf16_raw *out16; int out16_cs;        // optional: the block output in bf16 beside the e4m3 one
     int B, H, W;
     int tiles_x, tiles_y, ntiles;         // filled by the launcher
     unsigned *amax_mid, *amax_out;        // calibration (NULL = off): atomicMax of the bits of the tensors' maxima
@@ -226,12 +233,19 @@ hipError_t launch_upadd_backward(const bf16_raw *dy, const bf16_raw *out, int re
 struct UpAddFp8Params {
     const unsigned char *base; int base_cs; float base_scale;
     const unsigned char *up[3]; int up_cs[3]; int up_shift[3]; float up_scale[3]; int nup;
-    unsigned char *out; int out_cs;
+    // an operand given in bf16 (real values) instead of e4m3 * scale: base16 / up16[j] non-NULL take precedence
+    const bf16_raw *base16; int base16_cs;
+    const bf16_raw *up16[3]; int up16_cs[3];
+    unsigned char *out; int out_cs;       // optional e4m3 output
     float out_inv_scale;
+    bf16_raw *out16; int out16_cs;        // optional bf16 output
     int B, H, W, C, relu;
     unsigned *absmax;
 };
 hipError_t launch_upadd_fp8(const UpAddFp8Params &p, hipStream_t s);
+// bf16 tensor -> its e4m3 representation (q = e4m3(x * inv_scale)); n16 = groups of 16 channels per pixel; absmax: calibration
+hipError_t launch_quant_fp8(const bf16_raw *in, int in_cs, unsigned char *out, int out_cs, size_t npix, int C, float inv_scale, unsigned *absmax,
+                            hipStream_t s);
 
 // ClassificationHead tail: global average pool (bf16 NHWC -> fp32 [B,C]) and Linear (fp32)
 hipError_t launch_lds_poison(int num_cus, hipStream_t s);  // debug: NaN patterns into every CU's LDS (misc_kernels.hip)

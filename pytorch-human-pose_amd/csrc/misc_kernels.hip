@@ -119,6 +119,23 @@ __device__ __forceinline__ void fp8x16_fma(const uint4 q, float s, float v[16])
         v[4 * d + 2] = __builtin_fmaf(hi2[0], s, v[4 * d + 2]); v[4 * d + 3] = __builtin_fmaf(hi2[1], s, v[4 * d + 3]);
     }
 }
+__device__ __forceinline__ void bf16x16_add(const bf16_raw *src, float v[16])
+{
+    const uint4 a = reinterpret_cast<const uint4 *>(src)[0], b = reinterpret_cast<const uint4 *>(src)[1];
+    const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        v[2 * d + 0] += __builtin_bit_cast(float, w[d] << 16);
+        v[2 * d + 1] += __builtin_bit_cast(float, w[d] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ unsigned pack_bf16_pair(float a, float b)
+{
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_));
+}
 __global__ __launch_bounds__(256) void upadd_fp8_kernel(const UpAddFp8Params p)
 {
     const int cgn = p.C / 16;
@@ -133,31 +150,41 @@ __global__ __launch_bounds__(256) void upadd_fp8_kernel(const UpAddFp8Params p)
         float v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = 0.f;
-        fp8x16_fma(*reinterpret_cast<const uint4 *>(p.base + pix * p.base_cs + cg * 16), p.base_scale, v);
+        if (p.base16) bf16x16_add(p.base16 + pix * p.base16_cs + cg * 16, v);
+        else fp8x16_fma(*reinterpret_cast<const uint4 *>(p.base + pix * p.base_cs + cg * 16), p.base_scale, v);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (j < p.nup) {
                 const int sh = p.up_shift[j];
                 const size_t up = ((size_t)b * (p.H >> sh) + (y >> sh)) * (p.W >> sh) + (x >> sh);
-                fp8x16_fma(*reinterpret_cast<const uint4 *>(p.up[j] + up * p.up_cs[j] + cg * 16), p.up_scale[j], v);
+                if (p.up16[j]) bf16x16_add(p.up16[j] + up * p.up16_cs[j] + cg * 16, v);
+                else fp8x16_fma(*reinterpret_cast<const uint4 *>(p.up[j] + up * p.up_cs[j] + cg * 16), p.up_scale[j], v);
             }
-        unsigned w[4];
+        unsigned w[4], wb[8];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            float t[4];
+            float t[4], f4[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float f = v[4 * d + k];
                 if (p.relu) f = fmaxf(f, 0.f);
                 amax = fmaxf(amax, fabsf(f));
+                f4[k] = f;
                 t[k] = __builtin_amdgcn_fmed3f(f * p.out_inv_scale, -448.f, 448.f);
             }
             int q = 0;
             q = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], q, false);
             q = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], q, true);
             w[d] = (unsigned)q;
+            wb[2 * d] = pack_bf16_pair(f4[0], f4[1]);
+            wb[2 * d + 1] = pack_bf16_pair(f4[2], f4[3]);
         }
-        *reinterpret_cast<uint4 *>(p.out + pix * p.out_cs + cg * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        if (p.out) *reinterpret_cast<uint4 *>(p.out + pix * p.out_cs + cg * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        if (p.out16) {
+            uint4 *dst = reinterpret_cast<uint4 *>(p.out16 + pix * p.out16_cs + cg * 16);
+            dst[0] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+            dst[1] = make_uint4(wb[4], wb[5], wb[6], wb[7]);
+        }
     }
     if (p.absmax) {
 #pragma unroll
@@ -171,6 +198,51 @@ hipError_t launch_upadd_fp8(const UpAddFp8Params &p, hipStream_t s)
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL(upadd_fp8_kernel, dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// bf16 representation of a tensor -> its e4m3 one (fp8 plans: a tensor written by a bf16-kernel op and read by an fp8 conv)
+__global__ __launch_bounds__(256) void quant_fp8_kernel(const bf16_raw *__restrict__ in, int in_cs, unsigned char *__restrict__ out, int out_cs,
+                                                        size_t npix, int cgn, float inv_scale, unsigned *absmax)
+{
+    const size_t total = npix * cgn;
+    float amax = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cg = (int)(i % cgn);
+        const size_t pix = i / cgn;
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0.f;
+        bf16x16_add(in + pix * in_cs + cg * 16, v);
+        unsigned w[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                amax = fmaxf(amax, fabsf(v[4 * d + k]));
+                t[k] = __builtin_amdgcn_fmed3f(v[4 * d + k] * inv_scale, -448.f, 448.f);
+            }
+            int q = 0;
+            q = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], q, false);
+            q = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], q, true);
+            w[d] = (unsigned)q;
+        }
+        *reinterpret_cast<uint4 *>(out + pix * out_cs + cg * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (absmax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(absmax, __float_as_uint(amax));
+    }
+}
+hipError_t launch_quant_fp8(const bf16_raw *in, int in_cs, unsigned char *out, int out_cs, size_t npix, int C, float inv_scale, unsigned *absmax,
+                            hipStream_t s)
+{
+    const size_t total = npix * (C / 16);
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(quant_fp8_kernel, dim3(grid), dim3(256), 0, s, in, in_cs, out, out_cs, npix, C / 16, inv_scale, absmax);
     return hipGetLastError();
 }
 

@@ -1098,12 +1098,14 @@ def test_training_loop_reduces_the_loss(pkg):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # fp8 conv path (BASELINE.json configs[4]).  No reference precedent (the reference infers in fp32): parity is a STATED
-# tolerance against the fp32 goldens / oracle.  e4m3 keeps 3 mantissa bits (relative step 6-12 %), weights AND activations
-# are quantised, and every BasicBlock re-quantises the residual trunk, so on these random-weight nets the error grows like a
-# random walk over the ~60 layers: measured rms 4.6 % after the stem, 9-13 % through stages 1-2, 16-19 % at the outputs
-# (tools/fp8_check.py).  Stated tolerance: rms error <= 0.25 * rms(reference), max error <= 0.5 * max |reference|, and the
-# output must correlate > 0.95 with the fp32 reference.
-FP8_TOL_MAX, FP8_TOL_RMS, FP8_MIN_CORR = 0.5, 0.25, 0.95
+# tolerance against the fp32 goldens / oracle.  e4m3 keeps 3 mantissa bits: rounding a tensor to it costs 3.6 % rms, so a conv
+# whose weights and inputs are e4m3 leaves ~5 % on its output.  Round 3 keeps the residual trunk (block outputs, fusion sums) in
+# bf16 beside the e4m3 copy the next conv reads, and runs the three heads on the bf16 kernels: every block adds the error of its
+# two convs to the trunk instead of also re-rounding the trunk itself.  tools/probes/fp8_emulate.py reproduces both plans on the
+# CPU oracle with fake quantisation: 16-18 % rms at the outputs for the round-2 plan (what the round-2 engine measured), 6-9 %
+# for this one, of which ~5 % is the e4m3 WEIGHTS alone (activations in fp32) -- the floor of the format on these seeded nets.
+# Stated tolerance: rms error <= 0.10 * rms(reference), max error <= 0.20 * max |reference|, correlation >= 0.99.
+FP8_TOL_MAX, FP8_TOL_RMS, FP8_MIN_CORR = 0.20, 0.10, 0.99
 
 
 def _fp8_net(pkg, C, seed, calib_shape):
@@ -1156,6 +1158,60 @@ def test_fp8_w48_640_vs_oracle_and_batch_consistency(pkg):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+def test_fp8_bf16_trunk_beats_the_all_e4m3_plan(pkg, net_golden):
+    """The A/B behind the plan: HH_FP8_TRUNK=e4m3 HH_FP8_HEADS=e4m3 is round 2's plan (every tensor e4m3).  On the same weights,
+    calibration batch and input the default plan's output error must be well below it (emulation: 0.4-0.5x)."""
+    x = torch.from_numpy(pkg.synth.synth_images(2, 128, 128, 1)).to(DEV)
+    errs = {}
+    for name, env in (("trunk16", {}), ("all8", {"HH_FP8_TRUNK": "e4m3", "HH_FP8_HEADS": "e4m3"})):
+        with _switch_env(env):
+            net, _ = _fp8_net(pkg, 32, 1, (4, 128, 128))
+        hms, tags = net(x)
+        e = []
+        for got, ref in ((hms[0], net_golden["w32_128/hm_q"]), (hms[1], net_golden["w32_128/hm_h"]), (tags, net_golden["w32_128/tags"])):
+            got = got.cpu().numpy().astype(np.float64)
+            e.append(np.sqrt(((got - ref) ** 2).mean()) / np.sqrt((ref.astype(np.float64) ** 2).mean()))
+        errs[name] = e
+    print("fp8 rms errors (hm_q, hm_h, tags):", errs)
+    assert all(a <= FP8_TOL_RMS for a in errs["trunk16"]), errs
+    assert all(a < 0.7 * b for a, b in zip(errs["trunk16"], errs["all8"])), errs
+
+
+def test_fp8_chained_forward_decode_keeps_the_grouping(pkg):
+    """fp8 forward -> hh_decode as one chain on the pass-through net (constructed people carried from the input images to the
+    output maps) against fp32 oracle forward -> oracle decode: same number of people, same joints in the same groups, coordinates
+    within a pixel.  The carried values meet e4m3 once (the stem writes e4m3), so heatmap values and tags are rounded to 3 mantissa
+    bits: a person's tags may spread over one e4m3 step, 6-12 % of the tag's magnitude -- the images hold up to three people with
+    tags 1.7 / 3.4 / 5.1, whose steps (<= 0.5) stay inside tag_thr = 0.5 around the group mean; scores move by up to the same
+    relative step."""
+    net = pkg.HigherHRNet(17, 32, dtype="fp8")
+    sd = {k: torch.from_numpy(v) for k, v in pkg.synth.synth_passthrough_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 17, 0).items()}
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    B, hq, wq = 4, 64, 64
+    imgs, hms, fields = pkg.synth.synth_passthrough_images(B, hq, wq, [3, 2, 1, 3], 17, 1)
+    cal = pkg.synth.synth_passthrough_images(4, hq, wq, [3, 2, 1, 3], 17, 9)[0]
+    net.calibrate(torch.from_numpy(np.concatenate([cal, imgs])).to(DEV))
+    (g_hq, g_hh), g_tags = net(torch.from_numpy(imgs).to(DEV))
+    with torch.no_grad():
+        (r_hq, r_hh), r_tags = ofw.higher_hrnet(torch.from_numpy(imgs), sd, 17)
+    parser = pkg.MPPEHeatmapParser(17, 30, 0.05, 0.5)
+    got = parser.to_lists(*parser.decode_batch_device(g_hq, g_hh, [g_tags]))
+    max_dxy = max_ds = 0.0
+    for b in range(B):
+        rj, rs = orc.decode(r_hq[b].numpy(), r_hh[b].numpy(), [r_tags[b].numpy()], max_people=30, det_thr=0.05, tag_thr=0.5)
+        j, s_ = got[b]
+        assert j.shape == rj.shape, (b, j.shape, rj.shape)                  # same number of people
+        assert np.array_equal(j[..., 2] > 0, rj[..., 2] > 0), b              # same joints present in the same groups
+        max_dxy = max(max_dxy, float(np.abs(j[..., :2] - rj[..., :2]).max()))
+        max_ds = max(max_ds, float(np.abs(j[..., 2] - rj[..., 2]).max()))
+        # and the decode of the fp8 maps is the oracle's decode of those same maps, bit for bit
+        oj, os_ = orc.decode(g_hq[b].cpu().numpy(), g_hh[b].cpu().numpy(), [g_tags[b].cpu().numpy()], max_people=30, det_thr=0.05, tag_thr=0.5)
+        assert np.array_equal(j, oj) and np.array_equal(s_, os_)
+    print(f"fp8 chained: max |dxy| {max_dxy}, max |dscore| {max_ds}")
+    assert max_dxy <= 1.0 and max_ds <= 0.08, (max_dxy, max_ds)
+
+
 def test_fp8_requires_calibration_and_taps_track_the_reference(pkg, net_golden):
     net = pkg.HigherHRNet(17, 32, dtype="fp8")
     sd = {k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 0)) for k, v in net.state_dict().items()}
@@ -1172,7 +1228,9 @@ def test_fp8_requires_calibration_and_taps_track_the_reference(pkg, net_golden):
     n = 0
     for k in net_golden.files:  # every intermediate tensor of the reference, dequantised with its calibrated scale
         if k.startswith("w32_64/tap/") and k.split("/tap/")[1] in taps and k.split("/tap/")[1] != "deconv#1":
-            _fp8_close(taps[k.split("/tap/")[1]], net_golden[k], k)
+            e = _fp8_close(taps[k.split("/tap/")[1]], net_golden[k], k)
+            if "stem#0" in k or "stages.0" in k:  # two to fourteen convs deep: a mispacked tap or a wrong scale cannot hide here
+                assert e[1] <= 0.07, (k, e)
             n += 1
     assert n >= 60
     # new weights invalidate the scales

@@ -10,8 +10,11 @@ dev = "cuda:0"
 def err(got, ref):
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6), np.sqrt(((got - ref) ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-6)
-for dtype in ("bf16", "fp8"):
+VARIANTS = [("bf16", {}), ("fp8", {}), ("fp8", {"HH_FP8_HEADS": "e4m3"}), ("fp8", {"HH_FP8_TRUNK": "e4m3", "HH_FP8_HEADS": "e4m3"})]
+for dtype, env in VARIANTS:
+    os.environ.update(env)
     net = pkg.HigherHRNet(17, C, dtype=dtype)
+    for k in env: del os.environ[k]
     sd = {k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, seed)) for k, v in net.state_dict().items()}
     net.load_state_dict(sd)
     net = net.to(dev).eval()
@@ -23,7 +26,7 @@ for dtype in ("bf16", "fp8"):
     hms, tags = net(x)
     torch.cuda.synchronize()
     taps = net.read_taps()
-    print("==", dtype)
+    print("==", dtype, env or "")
     for k in g.files:
         if k.startswith(tag + "/tap/"):
             name = k.split("/tap/")[1]
