@@ -82,7 +82,9 @@ struct Geo {
 };
 }  // namespace
 
-template <int C>
+// T16: the trunk's bf16 representation is read as the residual (p.res16) and written beside the e4m3 output (p.out16);
+// a compile-time switch, so that the registers of the other residual path do not exist (the kernel sits at the 256-register limit)
+template <int C, bool T16>
 __global__ __launch_bounds__(NTHR, 1) void bb_fp8_kernel(const Fp8BBParams p)
 {
     using GE = Geo<C>;
@@ -217,6 +219,7 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fp8_kernel(const Fp8BBParams p)
                 __builtin_amdgcn_sched_group_barrier(0x8, NQ, 0);
             });
             // residual operands out of the patch centre before the patch buffer is recycled
+            if constexpr (!T16)
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fp8_kernel(const Fp8BBParams p)
                     fb[buf][q][1] = *reinterpret_cast<const u32x4 *>(lds_m + mbase + q * MW * PS + o1);
                 }
             };
-            if (p.res16) {  // in flight under conv2's MFMAs, consumed in its epilogue
+            if constexpr (T16) {  // in flight under conv2's MFMAs, consumed in its epilogue
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int oy = oy0 + part * 2 + q, ox = ox0 + r;
@@ -308,25 +311,25 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fp8_kernel(const Fp8BBParams p)
                 for (int g = 0; g < 4; ++g) {
                     const float4 mu = *reinterpret_cast<const float4 *>(lds_c + 2 * COUT_T + ct * 32 + 8 * g + 4 * h);
                     const float4 bs = *reinterpret_cast<const float4 *>(lds_c + 3 * COUT_T + ct * 32 + 8 * g + 4 * h);
-                    if (p.res16) {
+                    if constexpr (T16) {
                         y[4 * g + 0] = fmaxf(__builtin_bit_cast(float, resw[q][g][0] << 16) + __builtin_fmaf(acc2[q][4 * g + 0], mu.x, bs.x), 0.f);
                         y[4 * g + 1] = fmaxf(__builtin_bit_cast(float, resw[q][g][0] & 0xffff0000u) + __builtin_fmaf(acc2[q][4 * g + 1], mu.y, bs.y), 0.f);
                         y[4 * g + 2] = fmaxf(__builtin_bit_cast(float, resw[q][g][1] << 16) + __builtin_fmaf(acc2[q][4 * g + 2], mu.z, bs.z), 0.f);
                         y[4 * g + 3] = fmaxf(__builtin_bit_cast(float, resw[q][g][1] & 0xffff0000u) + __builtin_fmaf(acc2[q][4 * g + 3], mu.w, bs.w), 0.f);
-                        continue;
+                    } else {
+                        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)resq[q][g], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)resq[q][g], true);
+                        y[4 * g + 0] = fmaxf(__builtin_fmaf(lo[0], p.res_scale, __builtin_fmaf(acc2[q][4 * g + 0], mu.x, bs.x)), 0.f);
+                        y[4 * g + 1] = fmaxf(__builtin_fmaf(lo[1], p.res_scale, __builtin_fmaf(acc2[q][4 * g + 1], mu.y, bs.y)), 0.f);
+                        y[4 * g + 2] = fmaxf(__builtin_fmaf(hi[0], p.res_scale, __builtin_fmaf(acc2[q][4 * g + 2], mu.z, bs.z)), 0.f);
+                        y[4 * g + 3] = fmaxf(__builtin_fmaf(hi[1], p.res_scale, __builtin_fmaf(acc2[q][4 * g + 3], mu.w, bs.w)), 0.f);
                     }
-                    const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)resq[q][g], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)resq[q][g], true);
-                    y[4 * g + 0] = fmaxf(__builtin_fmaf(lo[0], p.res_scale, __builtin_fmaf(acc2[q][4 * g + 0], mu.x, bs.x)), 0.f);
-                    y[4 * g + 1] = fmaxf(__builtin_fmaf(lo[1], p.res_scale, __builtin_fmaf(acc2[q][4 * g + 1], mu.y, bs.y)), 0.f);
-                    y[4 * g + 2] = fmaxf(__builtin_fmaf(hi[0], p.res_scale, __builtin_fmaf(acc2[q][4 * g + 2], mu.z, bs.z)), 0.f);
-                    y[4 * g + 3] = fmaxf(__builtin_fmaf(hi[1], p.res_scale, __builtin_fmaf(acc2[q][4 * g + 3], mu.w, bs.w)), 0.f);
                 }
                 const bool valid = (oy < p.H) & (ox < p.W);
                 if (p.amax_out && valid)
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
                         if (ct * 32 + 8 * (i >> 2) < C) amax_out = fmaxf(amax_out, y[i]);
-                if (p.out16) {  // the block output as bf16 too (the next block's residual): couts 16h .. 16h+15 after the half exchange
+                if constexpr (T16) {  // the block output as bf16 too (the next block's residual): couts 16h .. 16h+15 after the half exchange
                     unsigned gd[4][2];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(NTHR, 1) void bb_fp8_kernel(const Fp8BBParams p)
     }
 }
 
-template <int C>
+template <int C, bool T16>
 static hipError_t launch_c(Fp8BBParams p, int num_cus, hipStream_t s)
 {
     static bool inited[64] = {};
@@ -377,7 +380,7 @@ static hipError_t launch_c(Fp8BBParams p, int num_cus, hipStream_t s)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!inited[dev & 63]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(bb_fp8_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<C>::LDS);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(bb_fp8_kernel<C, T16>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<C>::LDS);
         if (e != hipSuccess) return e;
         inited[dev & 63] = true;
     }
@@ -385,7 +388,7 @@ static hipError_t launch_c(Fp8BBParams p, int num_cus, hipStream_t s)
     p.tiles_y = (p.H + TH - 1) / TH;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     const int grid = p.ntiles < num_cus ? p.ntiles : num_cus;
-    HH_LAUNCH(bb_fp8_kernel<C>, dim3(grid), dim3(NTHR), Geo<C>::LDS, s, p);
+    HH_LAUNCH((bb_fp8_kernel<C, T16>), dim3(grid), dim3(NTHR), Geo<C>::LDS, s, p);
     return hipGetLastError();
 }
 
@@ -393,7 +396,9 @@ bool bb_fp8_supported(int C) { return C == 48 || C == 64; }
 
 hipError_t bb_fp8_launch(int C, const Fp8BBParams &p, int num_cus, hipStream_t s)
 {
-    if (C == 48) return launch_c<48>(p, num_cus, s);
-    if (C == 64) return launch_c<64>(p, num_cus, s);
+    const bool t16 = p.res16 && p.out16;
+    if ((p.res16 != nullptr) != (p.out16 != nullptr)) return hipErrorInvalidValue;  // both representations of the trunk or neither
+    if (C == 48) return t16 ? launch_c<48, true>(p, num_cus, s) : launch_c<48, false>(p, num_cus, s);
+    if (C == 64) return t16 ? launch_c<64, true>(p, num_cus, s) : launch_c<64, false>(p, num_cus, s);
     return hipErrorInvalidValue;
 }

@@ -143,8 +143,9 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(const Fp8ConvParams p)
 
     // the residual (fp8, 16 bytes = couts 16h..16h+15 of the lane's pixel and cout tile) is fetched now and consumed in
     // the epilogue
-    u32x4 rv[PT][NT];
-    u32x4 rw[PT][NT][2];  // bf16 residual: couts 16h .. 16h+7 and 16h+8 .. 16h+15 of the lane's pixel and cout tile
+    // one register array for both residual forms (the kernel sits near the register limit): bf16 = couts 16h .. 16h+7 and
+    // 16h+8 .. 16h+15 of the lane's pixel and cout tile in rw[..][0 / 1]; e4m3 = couts 16h .. 16h+15 in rw[..][0]
+    u32x4 rw[PT][NT][2];
     if (p.res16) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(const Fp8ConvParams p)
                 const int c0 = cg * COUT_T + nt * 32 + 16 * h;
                 const bool ok = valid && c0 < p.cout_store;
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(p.res + pix * p.res_cs + p.res_coff + (ok ? c0 : 0));
-                rv[pt][nt] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+                rw[pt][nt][0] = ok ? v : u32x4{0u, 0u, 0u, 0u};
             }
         }
     }
@@ -281,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(const Fp8ConvParams p)
             } else if (p.res) {
                 // 16 bytes = couts 16h .. 16h+15  ->  the accumulator layout (couts 8g + 4h + i): the two exchanges of the
                 // store path, backwards
-                auto t0 = __builtin_amdgcn_permlane32_swap(rv[pt][nt][0], rv[pt][nt][2], false, false);
-                auto t1 = __builtin_amdgcn_permlane32_swap(rv[pt][nt][1], rv[pt][nt][3], false, false);
+                auto t0 = __builtin_amdgcn_permlane32_swap(rw[pt][nt][0][0], rw[pt][nt][0][2], false, false);
+                auto t1 = __builtin_amdgcn_permlane32_swap(rw[pt][nt][0][1], rw[pt][nt][0][3], false, false);
                 // lane half 0: (t0[0], t1[0]) = couts 0..7, (t0[1], t1[1]) = 16..23; half 1: 8..15 and 24..31
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {

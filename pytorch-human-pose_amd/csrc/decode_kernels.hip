@@ -641,52 +641,22 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int l)
     return ((u64)hi << 32) | lo;
 }
 
-// Cost matrix of one joint + munkres.  -> 0 and `star` = the starred column of row `lane` (-1: none), or 1 if the iteration guard
-// ran out.  NMAX >= n = max(na, ng): the length of the unrolled loops (row `lane` / column `lane` live in NMAX registers).
-// Lane a builds ROW a in registers: cost(a, g) = rint(|tag_a - mean_g|) * 100 - score_a for the ng groups (the unrounded distance
-// goes to S.saved for the acceptance test), 1e10 for the columns the reference pads with when candidates outnumber groups
-// (grouping.py:126-128), zeros for the rows munkres pads with; step 1 (row minimum) runs on those registers, the reduced row goes to
-// LDS once and comes back transposed.
+// munkres on the n x n matrix in S.Cm.  -> 0 and `star` = the starred column of row `lane` (-1: none), or 1 if the iteration guard
+// ran out.  NMAX >= n: the length of the unrolled loops (row `lane`, then column `lane`, live in NMAX registers).
 template <int NMAX>
-__device__ int munkres_wave_n(MatchShared &S, int na, int ng, int E, int lane, int &star)
+__device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
 {
-    const int n = na > ng ? na : ng;
-    {
+    // step 1: subtract the row minimum (lane = row).  The row is read into registers in one go (a rolled loop waits for LDS once
+    // per element), reduced there and written back.
+    if (lane < n) {
         double rowv[NMAX];
-        const bool cand = lane < na;
-        const double sc = cand ? S.cj[lane * 3 + 2] : 0.0;
-        float ct[HH_MAX_EMB];
 #pragma unroll
-        for (int e = 0; e < HH_MAX_EMB; ++e) ct[e] = (cand && e < E) ? S.ctag[lane * HH_MAX_EMB + e] : 0.f;
-#pragma unroll
-        for (int g = 0; g < NMAX; ++g) {
-            double c = 0.0;  // munkres pad_matrix rows
-            if (g < n && cand) {
-                if (g < ng) {
-                    double ss = 0.0;
-#pragma unroll
-                    for (int e = 0; e < HH_MAX_EMB; ++e)
-                        if (e < E) {
-                            const double d = (double)ct[e] - (double)S.gmean[g * HH_MAX_EMB + e];
-                            ss = ss + d * d;
-                        }
-                    const double dist = __dsqrt_rn(ss);
-                    S.saved[lane * MLD + g] = dist;
-                    c = rint(dist) * 100.0 - sc;
-                } else {
-                    c = 1e10;  // grouping.py:126-128
-                }
-            }
-            rowv[g] = c;
-        }
-        // step 1: subtract the row minimum
+        for (int j = 0; j < NMAX; ++j) rowv[j] = S.Cm[lane * MLD + (j < n ? j : 0)];
         double mn = rowv[0];
 #pragma unroll
         for (int j = 1; j < NMAX; ++j) if (j < n && rowv[j] < mn) mn = rowv[j];
-        if (lane < n) {
 #pragma unroll
-            for (int j = 0; j < NMAX; ++j) if (j < n) S.Cm[lane * MLD + j] = rowv[j] - mn;
-        }
+        for (int j = 0; j < NMAX; ++j) if (j < n) S.Cm[lane * MLD + j] = rowv[j] - mn;
     }
     __syncthreads();
     double col[NMAX];  // column `lane`
@@ -791,13 +761,12 @@ __device__ int munkres_wave_n(MatchShared &S, int na, int ng, int E, int lane, i
 }
 
 // most images hold far fewer than HH_MAX_PEOPLE candidates per joint: the short instantiations skip the masked-off iterations
-__device__ __forceinline__ int munkres_wave(MatchShared &S, int na, int ng, int E, int lane, int &star)
+__device__ __forceinline__ int munkres_wave(MatchShared &S, int n, int lane, int &star)
 {
-    const int n = na > ng ? na : ng;
-    if (n <= 8) return munkres_wave_n<8>(S, na, ng, E, lane, star);
-    if (n <= 16) return munkres_wave_n<16>(S, na, ng, E, lane, star);
-    if (n <= 24) return munkres_wave_n<24>(S, na, ng, E, lane, star);
-    return munkres_wave_n<HH_MAX_PEOPLE>(S, na, ng, E, lane, star);
+    if (n <= 8) return munkres_wave_n<8>(S, n, lane, star);
+    if (n <= 16) return munkres_wave_n<16>(S, n, lane, star);
+    if (n <= 24) return munkres_wave_n<24>(S, n, lane, star);
+    return munkres_wave_n<HH_MAX_PEOPLE>(S, n, lane, star);
 }
 
 __constant__ int c_joints_order[17] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 7, 8, 9, 10, 13, 14, 15, 16};  // grouping.py:63-65
@@ -854,8 +823,32 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
                 else np_mean_rows(GT + (size_t)lane * (K + 1) * E, nt, E, &S.gmean[lane * HH_MAX_EMB]);
             }
             __syncthreads();
+            const int n = na > ng ? na : ng;
+            const float inv_n = 1.0f / (float)n;
+            for (int i = lane; i < n * n; i += 64) {
+                // (a, g) = (i / n, i % n) without an integer division: (i + 0.5) / n is at least 1 / (2n) >= 1/64 away from an integer,
+                // far beyond the float error of the product for i < 1024
+                const int a = (int)(((float)i + 0.5f) * inv_n), g = i - a * n;
+                double c = 0.0;  // munkres pad_matrix rows
+                if (a < na) {
+                    if (g < ng) {
+                        double ss = 0.0;
+                        for (int e = 0; e < E; ++e) {
+                            const double d = (double)S.ctag[a * HH_MAX_EMB + e] - (double)S.gmean[g * HH_MAX_EMB + e];
+                            ss = ss + d * d;
+                        }
+                        const double dist = __dsqrt_rn(ss);
+                        S.saved[a * MLD + g] = dist;
+                        c = rint(dist) * 100.0 - S.cj[a * 3 + 2];
+                    } else {
+                        c = 1e10;  // grouping.py:126-128
+                    }
+                }
+                S.Cm[a * MLD + g] = c;
+            }
+            __syncthreads();
             int star = -1;
-            bad |= munkres_wave(S, na, ng, E, lane, star);
+            bad |= munkres_wave(S, n, lane, star);
             if (lane < na) S.assign[lane] = star;
             __syncthreads();
         }

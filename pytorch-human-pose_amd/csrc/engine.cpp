@@ -31,6 +31,14 @@ PlanSwitches PlanSwitches::from_env()
     s.no_fusion_merge = on("HH_NO_FUSION_MERGE");
     s.poison_ws = on("HH_POISON_WS");
     s.poison_lds = on("HH_POISON_LDS");
+    if (const char *sk = getenv("HH_DEBUG_SKIP")) {
+        static const struct { const char *name; unsigned bit; } cats[] = {{"s2big", SK_S2BIG}, {"s2", SK_S2}, {"upadd", SK_UPADD}, {"c1x1", SK_C1X1},
+            {"c256", SK_C256}, {"c128", SK_C128}, {"junc", SK_JUNC}, {"bb32", SK_BB32}, {"bb64", SK_BB64}, {"stem", SK_STEM}, {"deconv", SK_DECONV},
+            {"head", SK_HEAD}, {"trans0", SK_TRANS0}};
+        std::string v = std::string(",") + sk + ",";
+        for (const auto &c : cats)
+            if (v.find(std::string(",") + c.name + ",") != std::string::npos) s.debug_skip |= c.bit;
+    }
     s.fp8_trunk8 = is("HH_FP8_TRUNK", "e4m3");
     s.fp8_heads8 = is("HH_FP8_HEADS", "e4m3");
     return s;
@@ -310,7 +318,7 @@ struct Builder {
             cb(up, "conv2", "bn2", 64, 64, 3, 1, t1, t2u, 1);
             if (n.dtype == 2) {  // layer by layer (hrnet.py:58-74): downsample, conv3 + residual + ReLU, next unit's conv1
                 if (u == 0) cb(up, "downsample.0", "downsample.1", 64, 256, 1, 1, X, DS, 0);
-                cb(up, "conv3", "bn3", 64, 256, 1, 1, t2, Y, 1, u == 0 ? DS : Y);
+                cb(up, "conv3", "bn3", 64, 256, 1, 1, t2, Y, 1, u == 0 ? DS : Y).res8 = true;
                 if (u < 3) cb(unit(u + 1), "conv1", "bn1", 256, 64, 1, 1, Y, t1, 1);
                 continue;
             }
@@ -561,7 +569,7 @@ void hh_net::assign_fp8_formats()
         case OP_STEM: need8(op.out); break;  // stem_conv.hip writes e4m3 only
         case OP_CONV:
             if (op.hi) { if (op.in >= 0) tensors[op.in].b16 = true; if (op.out >= 0) tensors[op.out].b16 = true; }
-            else { need8(op.in); need16(op.res); }
+            else { need8(op.in); if (op.res8) need8(op.res); else need16(op.res); }
             break;
         case OP_BB: need8(op.in); need16(op.in); break;
         case OP_UPADD: need16(op.in); for (int j = 0; j < op.nup; ++j) need16(op.up[j]); break;
@@ -873,6 +881,24 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
     hipEvent_t mark_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     for (const Op &op : ops) {
         hipStream_t s = L[op.lane];
+        if (sw.debug_skip) {  // measurement only: the outputs are wrong
+            unsigned cat = 0;
+            if (op.kind == OP_UPADD) cat = SK_UPADD;
+            else if (op.kind == OP_JUNC) cat = SK_JUNC;
+            else if (op.kind == OP_STEM) cat = SK_STEM;
+            else if (op.kind == OP_BB) cat = layers[op.layer].cout == 32 ? SK_BB32 : layers[op.layer].cout == 64 ? SK_BB64 : 0;
+            else if (op.kind == OP_CONV) {
+                const ConvLayer &l = layers[op.layer];
+                if (l.transposed) cat = SK_DECONV;
+                else if (op.f32_out) cat = SK_HEAD;
+                else if (l.stride == 2) cat = SK_S2 | (l.cin >= 128 ? SK_S2BIG : 0) | (l.cin == 256 && l.mconv.empty() && tensors[op.in].shift == 2 ? SK_TRANS0 : 0);
+                else if (l.ks == 1) cat = SK_C1X1;
+                else if (l.cin == 256 && l.cout == 256) cat = SK_C256;
+                else if (l.cin == 128 && l.cout == 128) cat = SK_C128;
+                else if (l.cin == 256 && tensors[op.in].shift == 2) cat = SK_TRANS0;
+            }
+            if (cat & sw.debug_skip) continue;
+        }
         if (sw.poison_lds && op.kind != OP_JOIN && op.kind != OP_MARK && op.kind != OP_WAITL && op.kind != OP_DEP && op.kind != OP_TAP)
             HH_CHECK_HIP(launch_lds_poison(num_cus, s));
         switch (op.kind) {

@@ -83,6 +83,8 @@ struct Op {
     int up[3] = {-1, -1, -1}, up_shift[3] = {0, 0, 0}, nup = 0;
     int C = 0;  // UPADD channel count / TAP channel count
     int tap = -1;
+    bool res8 = false;  // fp8 handle: this conv's residual stays e4m3 (stage 0's 256-channel trunk: its 1x1 convs are HBM-bound and a bf16
+                        // twin would triple their traffic; emulation: +0.3-0.5 % rms at the outputs)
     bool hi = false;  // fp8 handle: OP_CONV on the bf16 kernels over the tensors' bf16 representations; OP_QUANT: tensor `out`'s bf16 -> e4m3
     int lane = 0;     // execution lane (HIP stream): resolution branches / fusion outputs run concurrently
     int nlanes = 0;   // OP_JOIN: all-to-all barrier over lanes [0, nlanes)
@@ -130,10 +132,15 @@ struct PlanSwitches {
     bool no_fusion_merge = false;  // HH_NO_FUSION_MERGE=1: one launch per summed stride-2 conv of a fusion layer
     bool poison_ws = false;        // HH_POISON_WS=1 (tests): workspace filled with NaN patterns at allocation
     bool poison_lds = false;       // HH_POISON_LDS=1 (tests): every CU's LDS filled with NaN patterns in front of every launch
+    unsigned debug_skip = 0;       // HH_DEBUG_SKIP=cat[,cat..] (measurement only, results are WRONG): launches of these categories are not
+                                   // issued -- how much of the forward's wall time hangs on a kernel family (tools/probes/skip_sensitivity.sh)
     bool fp8_trunk8 = false;       // HH_FP8_TRUNK=e4m3: fp8 handles re-quantise the residual trunk to e4m3 in every block (the round-2 plan)
     bool fp8_heads8 = false;       // HH_FP8_HEADS=e4m3: the two 1x1 heads and the transposed conv of an fp8 handle on the e4m3 kernels too
     static PlanSwitches from_env();
 };
+
+enum SkipCat { SK_S2BIG = 1, SK_S2 = 2, SK_UPADD = 4, SK_C1X1 = 8, SK_C256 = 16, SK_C128 = 32, SK_JUNC = 64, SK_BB32 = 128, SK_BB64 = 256,
+               SK_STEM = 512, SK_DECONV = 1024, SK_HEAD = 2048, SK_TRANS0 = 4096 };
 
 struct hh_net {
     int K, C, dtype;

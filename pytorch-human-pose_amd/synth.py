@@ -258,7 +258,8 @@ def synth_passthrough_state_dict(shapes: dict, num_kpts: int = 17, seed: int = 0
     return sd
 
 
-def synth_passthrough_images(batch: int, hq: int, wq: int, num_people, num_kpts: int = 17, seed: int = 0, tag_gain: float = 1.0):
+def synth_passthrough_images(batch: int, hq: int, wq: int, num_people, num_kpts: int = 17, seed: int = 0, tag_gain: float = 1.0,
+                             sigma: float = 2.0):
     """Images [B,3,4hq,4wq] for a pass-through net: constructed quarter-res heatmaps (synth_decode_maps) and one tag field per
     image (per pixel the tag of the strongest blob there), rounded to bf16-exact values, written into the reserved slots of
     every 4x4x3 block; all other pixels ~ N(0,1).  Returns (images, hm_q [B,K,hq,wq], tag_field [B,hq,wq])."""
@@ -275,7 +276,7 @@ def synth_passthrough_images(batch: int, hq: int, wq: int, num_people, num_kpts:
 
     for i in range(batch):
         P = num_people[i % len(num_people)] if isinstance(num_people, (list, tuple)) else num_people
-        hm_q, _, _, people = synth_decode_maps(K, hq, wq, P, seed=seed * 1000 + i)
+        hm_q, _, _, people = synth_decode_maps(K, hq, wq, P, seed=seed * 1000 + i, sigma=sigma)
         field = np.abs(0.05 * rs.standard_normal((hq, wq))).astype(np.float32)
         best = np.zeros((hq, wq), np.float32)
         for p in range(P):

@@ -5,7 +5,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 pkg = importlib.import_module("pytorch-human-pose_amd")
 K, H, W, B = 17, 512, 512, 32
-uniq = [pkg.synth.synth_decode_maps(K, H // 4, W // 4, 10, seed=1000 + i)[:3] for i in range(8)]
+P = int(os.environ.get("HH_DECODE_PEOPLE") or 10)
+uniq = [pkg.synth.synth_decode_maps(K, H // 4, W // 4, P, seed=(1000 if P == 10 else 5000) + i)[:3] for i in range(8)]
 hm_q = torch.from_numpy(np.stack([uniq[i % 8][0] for i in range(B)])).cuda()
 hm_h = torch.from_numpy(np.stack([uniq[i % 8][1] for i in range(B)])).cuda()
 tags = torch.from_numpy(np.stack([uniq[i % 8][2][0] for i in range(B)])).cuda()

@@ -48,12 +48,14 @@ def store(y, trunk):
     if MODE == "W": return y
     return b16(y)
 
+STAGE0_E4M3 = False  # stage 0's 256-channel trunk e4m3 only (no bf16 twin): 3x less HBM traffic in its HBM-bound 1x1 convs
 def bottleneck(x, p, lowp):
-    y = store(conv_bn(x, p, "conv1", "bn1", relu=True, lowp=lowp), False)
-    y = store(conv_bn(y, p, "conv2", "bn2", relu=True, lowp=lowp), False)
+    st = (lambda t, trunk: q8(t)) if (STAGE0_E4M3 and MODE == "B") else store
+    y = st(conv_bn(x, p, "conv1", "bn1", relu=True, lowp=lowp), False)
+    y = st(conv_bn(y, p, "conv2", "bn2", relu=True, lowp=lowp), False)
     y = conv_bn(y, p, "conv3", "bn3", lowp=lowp)
-    r = store(conv_bn(x, p, "downsample.0", "downsample.1", lowp=lowp), False) if p.has("downsample.0.weight") else x
-    return store(F.relu(y + r), True)
+    r = st(conv_bn(x, p, "downsample.0", "downsample.1", lowp=lowp), False) if p.has("downsample.0.weight") else x
+    return st(F.relu(y + r), True)
 
 def basic(x, p, lowp=True):
     y = store(conv_bn(x, p, "conv1", "bn1", relu=True, lowp=lowp), False)
@@ -133,6 +135,7 @@ with torch.no_grad():
     def rep(tag, hms, tags):
         e = lambda a, b: (float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt()), float((a - b).abs().max() / b.abs().max()))
         print(f"{tag:4s} hm_q rms {e(hms[0], rh[0])[0]:.4f} max {e(hms[0], rh[0])[1]:.4f} | hm_h rms {e(hms[1], rh[1])[0]:.4f} max {e(hms[1], rh[1])[1]:.4f} | tags rms {e(tags, rt)[0]:.4f} max {e(tags, rt)[1]:.4f}", flush=True)
-    for mode, hp, hh in (("W", False, False), ("A", False, False), ("B", False, False), ("B", True, True), ("B", False, True), ("B", True, False)):
+    for mode, hp, hh, s0 in (("W", False, False, False), ("A", False, False, False), ("B", False, False, False), ("B", True, True, False), ("B", False, True, False), ("B", True, False, False), ("B", False, True, True)):
         MODE = mode
-        rep(mode + ("s" if hp else "") + ("h" if hh else ""), *forward(x, sd, 17, hp, hh))
+        STAGE0_E4M3 = s0
+        rep(mode + ("s" if hp else "") + ("h" if hh else "") + ("0" if s0 else ""), *forward(x, sd, 17, hp, hh))
