@@ -424,7 +424,6 @@ def main():
             names = {100: "bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)" if os.environ.get("HH_BB32") == "tile" else
                           "bbpc_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32, producer/consumer waves)",
                      105: "bb_fp8_kernel (fused e4m3 BasicBlock: conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU)",
-                     104: "bb128_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=128)",
                      103: "bb64_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=64)",
                      102: "stem_conv_kernel (fp32 NCHW -> conv3x3 s2 3->64 + BN + ReLU -> bf16 NHWC)",
                      106: "stem_fused_kernel (fp32 NCHW -> conv3x3 s2 3->64 + BN + ReLU -> conv3x3 s2 64->64 + BN + ReLU -> bf16 NHWC)",

@@ -23,7 +23,6 @@ PlanSwitches PlanSwitches::from_env()
     PlanSwitches s;
     s.bb32_tile = is("HH_BB32", "tile");
     s.no_bb64 = on("HH_NO_BB64");
-    s.bb128 = is("HH_BB128", "all") ? 2 : is("HH_BB128", "stage2") ? 1 : 0;
     s.no_bb_fp8 = on("HH_NO_BB_FP8");
     s.no_stem_fused = on("HH_NO_STEM_FUSED");
     s.no_junc_pair = on("HH_NO_JUNC_PAIR");
@@ -31,6 +30,7 @@ PlanSwitches PlanSwitches::from_env()
     s.no_fusion_merge = on("HH_NO_FUSION_MERGE");
     s.poison_ws = on("HH_POISON_WS");
     s.poison_lds = on("HH_POISON_LDS");
+    s.no_head_fold = on("HH_NO_HEAD_FOLD");
     if (const char *sk = getenv("HH_DEBUG_SKIP")) {
         static const struct { const char *name; unsigned bit; } cats[] = {{"s2big", SK_S2BIG}, {"s2", SK_S2}, {"upadd", SK_UPADD}, {"c1x1", SK_C1X1},
             {"c256", SK_C256}, {"c128", SK_C128}, {"junc", SK_JUNC}, {"bb32", SK_BB32}, {"bb64", SK_BB64}, {"stem", SK_STEM}, {"deconv", SK_DECONV},
@@ -243,21 +243,18 @@ struct Builder {
     // `nscales` = number of resolution branches running beside this one (0: no siblings, e.g. the deconv head)
     void basic_blocks(const std::string &prefix, int C, int x, int m, int nscales = 0, int branch = 0)
     {
-        // The fused 128-channel block (basicblock_fused_c128.hip: 25.7 us per block against 2 x 18.4 us layer by layer when the
-        // kernels run one at a time) is OFF by default: with the branch lanes running side by side it loses -- one box, two
-        // alternations: 5512 / 5511 img/s without it, 5451 / 5432 with it in stage 2 only, 5395 / 5415 everywhere.  Its 150 KB
-        // workgroups take whole CUs, while the layer-by-layer launches (64 KB workgroups) share CUs with each other and with
-        // the 256-channel branch.  HH_BB128=all | stage2 enables it (serial execution, experiments).
-        const bool bb128 = C == 128 && (n.sw.bb128 == 2 || (n.sw.bb128 == 1 && nscales == 3));
+        // (A fused 128-channel block existed in rounds 2-3, 25.7 us per block against 2 x 17.7 us layer by layer when run alone; with
+        // the branch lanes side by side it LOST every A/B -- round 3, one box, three alternations: forward 4.72 / 4.75 / 4.73 ms
+        // without, 4.86 / 4.85 / 4.83 ms with it, profiles/r03_ab.md -- because its 150 KB workgroups own their CUs while the
+        // layer-by-layer launches share CUs with the 256-channel branch.  Removed; `git log` has it.)
         for (int u = 0; u < 4; ++u) {
             const std::string up = prefix + "." + std::to_string(u);
             const bool fused_fp8 = n.dtype == 2 && bb_fp8_supported(C) && branch == 0 && !n.sw.no_bb_fp8;  // highest-resolution branch / deconv head
-            if (((C == 32 || (C == 64 && !n.sw.no_bb64) || bb128) && n.dtype != 2) || fused_fp8) {  // fused kernels, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
+            if (((C == 32 || (C == 64 && !n.sw.no_bb64)) && n.dtype != 2) || fused_fp8) {  // fused kernels, ping-pong x <-> m (a tile reads its neighbours' halo: no in-place)
                 Op o;
                 o.kind = OP_BB;
                 o.layer = L(up + ".conv1", up + ".bn1", C, C, 3, 1);
                 o.layer2 = L(up + ".conv2", up + ".bn2", C, C, 3, 1);
-                n.layers[o.layer].bb128 = n.layers[o.layer2].bb128 = (C == 128);
                 o.in = (u & 1) ? m : x;
                 o.out = (u & 1) ? x : m;
                 o.lane = lane;
@@ -354,9 +351,13 @@ struct Builder {
         tap("stages.0#0", x[0], w[0]);
         tap("stages.0#1", x[1], w[1]);
 
-        const int catC = round_up(C + 2 * K, 16);
+        // bf16 handles fold init_heatmaps_head into the transposed conv (ConvLayer::fold_w): the buffer is [feats | 1 | zero pad] and
+        // the 1x1 head leaves the chain of dependent launches (it runs beside the deconv head on lane 1)
+        const bool head_fold = n.dtype != 2 && n.kind == 0 && !n.sw.no_head_fold;
+        const int catC = head_fold ? round_up(C + 1, 16) : round_up(C + 2 * K, 16);
         const int CAT = T(catC, 2, true);  // [feats | init heatmaps | zero pad] = torch.cat of higher_hrnet.py:73
         n.tensors[CAT].shared_scale = true;
+        if (head_fold) n.tensors[CAT].ones_channel = C;
 
         const int nblocks[4] = {1, 1, 4, 3};
         for (int s = 1; s < 4; ++s) {
@@ -514,7 +515,13 @@ struct Builder {
         // the bf16 representations: their e4m3 rounding lands on the outputs undamped (tools/probes/fp8_emulate.py: 7.8 -> 6.4 %
         // rms on the tags of W48).  HH_FP8_HEADS=e4m3 keeps them on the e4m3 kernels.
         const bool hi_heads = n.dtype == 2 && !n.sw.fp8_heads8;
-        {
+        if (head_fold) {  // fp32 result only, off the main lane: lane 1 waits for the last fusion (lane 0) and is collected at the end
+            dep(0, 1);
+            lane = 1;
+            Op &o = conv(L("init_heatmaps_head", "", C, 2 * K, 1, 1, "init_heatmaps_head.bias"), CAT, -1, 0);
+            o.f32_out = 1;
+            lane = 0;
+        } else {
             Op &o = conv(L("init_heatmaps_head", "", C, 2 * K, 1, 1, "init_heatmaps_head.bias"), CAT, CAT, 0);
             o.out_coff = C; o.cout_store = catC - C; o.f32_out = 1;
             o.hi = hi_heads; n.layers[o.layer].hi = hi_heads;
@@ -523,8 +530,10 @@ struct Builder {
         const std::string dp = "deconv_layers.0";
         const int DF = T(C, 1), DM = T(C, 1);
         {   // one launch: the four phase weight sets are packed back to back (py = -1 marks "all phases")
-            const int l = L(dp + ".deconv.0", dp + ".deconv.1", C + 2 * K, C, 2, 1);
+            const int l = L(dp + ".deconv.0", dp + ".deconv.1", head_fold ? C + 1 : C + 2 * K, C, 2, 1);
             n.layers[l].transposed = true; n.layers[l].py = -1; n.layers[l].px = -1;
+            n.layers[l].acct_cin = C + 2 * K;
+            if (head_fold) { n.layers[l].fold_w = "init_heatmaps_head.weight"; n.layers[l].fold_b = "init_heatmaps_head.bias"; }
             Op &o = conv(l, CAT, DF, 1);
             o.scatter = 1;
             o.hi = hi_heads; n.layers[l].hi = hi_heads;
@@ -631,7 +640,6 @@ int hh_net::finalize()
     HH_CHECK_HIP(stem_fused_init());
     HH_CHECK_HIP(bbpc_init());
     HH_CHECK_HIP(bb64_fused_init());
-    HH_CHECK_HIP(bb128_fused_init());
     HH_CHECK_HIP(junction_init());
     if (dtype == 2 && kind != 0) { hh_set_error("hh_finalize: the fp8 path covers HigherHRNet only"); return 1; }
     {
@@ -667,8 +675,7 @@ int hh_net::finalize()
         }
         if (dtype == 2 && !l.hi) continue;  // e4m3 weights: finalize_fp8() below
         const int cin_pad0 = round_up(l.cin, 16), coutp = round_up(l.cout, 32);
-        if (l.bb128) { l.KC = 16; l.NT = 4; }  // basicblock_fused_c128.hip: [chunk of 16 cin][tap][2][128 couts][8]
-        else if (l.stem2) { l.KC = 64; l.NT = 2; }  // stem_fused.hip: [tap][8][64 couts][8]
+        if (l.stem2) { l.KC = 64; l.NT = 2; }  // stem_fused.hip: [tap][8][64 couts][8]
         else if (hh_family_pick(l.ks, l.stride, cin_pad0, coutp, &l.KC, &l.NT)) {
             hh_set_error("no kernel family for conv " + l.conv);
             return 1;
@@ -704,7 +711,21 @@ int hh_net::finalize()
             HH_CHECK_HIP(hipMemcpy(l.d_bias, shift.data(), (size_t)coutp * 4, hipMemcpyHostToDevice));
             continue;
         }
-        const std::vector<float> &W = get(l.conv + ".weight");
+        std::vector<float> Wfold;
+        if (!l.fold_w.empty()) {  // [C + 1, cout, 4, 4]: rows 0..C-1 = Wd_feats + sum_k Wf[k, c] * Wd_hm[k], row C = sum_k bf[k] * Wd_hm[k]
+            const std::vector<float> &Wd = get(l.conv + ".weight"), &Wf = get(l.fold_w), &bf = get(l.fold_b);
+            const int Cf = l.cin - 1, K2 = (int)bf.size();
+            Wfold.assign((size_t)l.cin * l.cout * 16, 0.f);
+            for (int c = 0; c <= Cf; ++c)
+                for (int co = 0; co < l.cout; ++co)
+                    for (int t = 0; t < 16; ++t) {
+                        double acc = c < Cf ? (double)Wd[((size_t)c * l.cout + co) * 16 + t] : 0.0;
+                        for (int k = 0; k < K2; ++k)
+                            acc += (double)(c < Cf ? Wf[(size_t)k * Cf + c] : bf[k]) * (double)Wd[((size_t)(Cf + k) * l.cout + co) * 16 + t];
+                        Wfold[((size_t)c * l.cout + co) * 16 + t] = (float)acc;
+                    }
+        }
+        const std::vector<float> &W = Wfold.empty() ? get(l.conv + ".weight") : Wfold;
         std::vector<float> scale(coutp, 0.f), shift(coutp, 0.f);
         for (int co = 0; co < l.cout; ++co) {
             if (!l.bn.empty()) {
@@ -789,6 +810,12 @@ int hh_net::reserve(int B, int H, int W)
             if (alloc(bytes, (void **)&t.ptr)) return 1;
             if (sw.poison_ws) HH_CHECK_HIP(hipMemset(t.ptr, 0xFF, bytes));
             if (t.zero_init) HH_CHECK_HIP(hipMemset(t.ptr, 0, bytes));
+            if (t.ones_channel >= 0 && dtype != 2) {  // bf16 1.0 = 0x3F80 in channel `ones_channel` of every pixel
+                const size_t npix = (size_t)nB * (nH >> t.shift) * (nW >> t.shift);
+                char *c0 = (char *)t.ptr + (size_t)t.ones_channel * 2;
+                HH_CHECK_HIP(hipMemset2D(c0, (size_t)t.C * 2, 0x80, 1, npix));
+                HH_CHECK_HIP(hipMemset2D(c0 + 1, (size_t)t.C * 2, 0x3F, 1, npix));
+            }
         }
         if (dtype == 2 && t.b16) {
             if (alloc(n * 2, (void **)&t.ptr16)) return 1;
@@ -1109,15 +1136,14 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr = &prof[prof_used++];
                 pr->op = (int)(&op - ops.data());
                 const double Cb = l1.cout;
-                pr->cfg = l1.cout == 128 ? HH_CFG_BB128_FUSED : l1.cout == 64 ? HH_CFG_BB64_FUSED : HH_CFG_BB_FUSED;
+                pr->cfg = l1.cout == 64 ? HH_CFG_BB64_FUSED : HH_CFG_BB_FUSED;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
                 if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 4 * pr->slot;
                 pr->flops = 2.0 * 2.0 * B * p.H * p.W * Cb * Cb * 9.0;
                 pr->bytes = 2.0 * B * p.H * p.W * Cb * 2 + 2.0 * 2 * 9 * Cb * Cb;
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
             }
-            if (l1.cout == 128) HH_CHECK_HIP(bb128_fused_launch(p, num_cus, s));
-            else if (l1.cout == 64) HH_CHECK_HIP(bb64_fused_launch(p, num_cus, s));
+            if (l1.cout == 64) HH_CHECK_HIP(bb64_fused_launch(p, num_cus, s));
             else if (!sw.bb32_tile && bbpc_supported(p)) HH_CHECK_HIP(bbpc_launch(p, num_cus, s));
             else HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
             break;
@@ -1201,11 +1227,12 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->cfg = cfg;
                 pr->slot = prof_used <= HH_PROF_SLOTS ? (int)prof_used - 1 : -1;
                 if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 4 * pr->slot;
-                pr->flops = 2.0 * B * p.Ho * p.Wo * (double)l.cin * l.cout * l.ks * l.ks * (p.nphase > 1 ? 4 : 1);
+                const double acin = l.acct_cin ? l.acct_cin : l.cin;  // (algorithmic: the reference layer's input width)
+                pr->flops = 2.0 * B * p.Ho * p.Wo * acin * l.cout * l.ks * l.ks * (p.nphase > 1 ? 4 : 1);
                 {
                     const double opix = (double)B * p.Ho * p.Wo * (p.nphase > 1 ? 4 : 1);
-                    pr->bytes = 2.0 * B * p.Hin * p.Win * l.cin + (p.out ? 2.0 * opix * l.cout : 0.0) + (p.res ? 2.0 * opix * l.cout : 0.0) +
-                                (p.out_f32 ? 4.0 * opix * l.cout : 0.0) + 2.0 * l.cin * l.cout * l.ks * l.ks * (p.nphase > 1 ? 4 : 1);
+                    pr->bytes = 2.0 * B * p.Hin * p.Win * acin + (p.out ? 2.0 * opix * l.cout : 0.0) + (p.res ? 2.0 * opix * l.cout : 0.0) +
+                                (p.out_f32 ? 4.0 * opix * l.cout : 0.0) + 2.0 * acin * l.cout * l.ks * l.ks * (p.nphase > 1 ? 4 : 1);
                 }
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
             }
@@ -1371,7 +1398,7 @@ double hh_net::flops(int B, int H, int W) const
         const double hin = H >> ti.shift, win = W >> ti.shift;
         const double ho = l.stride == 2 ? hin / 2 : hin, wo = l.stride == 2 ? win / 2 : win;
         // a transposed-conv phase: every input pixel meets 4 of the 16 taps per phase (16 over the 4 phases)
-        macs += ho * wo * (double)l.cin * l.cout * l.ks * l.ks * ((l.transposed && l.py < 0) ? 4 : 1);
+        macs += ho * wo * (double)(l.acct_cin ? l.acct_cin : l.cin) * l.cout * l.ks * l.ks * ((l.transposed && l.py < 0) ? 4 : 1);
     }
     if (kind == 1) macs += 2048.0 * num_classes;
     return 2.0 * macs * B;

@@ -38,8 +38,13 @@ struct ConvLayer {
     std::vector<int> mcin;
     bool stem2 = false; // second stem conv inside stem_fused.hip: packed [tap][cin/8][64 couts][8]
     bool stem = false;  // first conv of the net: packed for stem_conv.hip (K = 27 taps padded to 32)
-    bool bb128 = false; // conv of a fused 128-channel BasicBlock: packed with 16-channel chunks over all 128 couts
     bool hi = false;    // fp8 handle: this layer runs on the bf16 kernels (the heads), packed like a bf16 handle's
+    // The transposed conv with init_heatmaps_head folded in (bf16 handles): torch.cat((feats, head(feats))) followed by a linear
+    // op is linear in feats, so the layer reads [feats | 1] with W_eff = Wd_feats + Wd_hm * Wf and the head's bias on the
+    // constant-one channel (which is 0 outside the image like every other channel, so the borders stay exact).  fold_w / fold_b:
+    // the head's state-dict keys; acct_cin: the input width the FLOP accounting keeps (the reference's C + 2K)
+    std::string fold_w, fold_b;
+    int acct_cin = 0;
     int py = 0, px = 0;  // phase of the transposed conv this entry implements (-1: all four, packed back to back)
     size_t phase_stride = 0;
     // chosen at finalize
@@ -61,6 +66,7 @@ struct TensorDesc {
     bool f8 = true, b16 = false;
     bf16_raw *ptr16 = nullptr;
     bool zero_init = false;
+    int ones_channel = -1;  // >= 0: this channel holds 1.0 in every pixel (written at reserve, never by a kernel)
     bool shared_scale = false;  // fp8: written in channel slices by several ops (torch.cat buffer): one scale for all of them
 };
 
@@ -124,13 +130,13 @@ struct GraphEntry {
 struct PlanSwitches {
     bool bb32_tile = false;        // HH_BB32=tile: basicblock_fused.hip instead of the producer / consumer form
     bool no_bb64 = false;          // HH_NO_BB64=1: 64-channel BasicBlocks layer by layer
-    int bb128 = 0;                 // HH_BB128=all (2) | stage2 (1): fused 128-channel BasicBlock (off by default: loses beside the lanes)
     bool no_bb_fp8 = false;        // HH_NO_BB_FP8=1: fp8 BasicBlocks layer by layer
     bool no_stem_fused = false;    // HH_NO_STEM_FUSED=1: the stem as two launches
     bool no_junc_pair = false;     // HH_NO_JUNC_PAIR=1: every stage-0 junction stores its 256-channel output
     bool full_join = false;        // HH_FULL_JOIN=1: all-to-all joins of the branch lanes instead of per-source waits
     bool no_fusion_merge = false;  // HH_NO_FUSION_MERGE=1: one launch per summed stride-2 conv of a fusion layer
     bool poison_ws = false;        // HH_POISON_WS=1 (tests): workspace filled with NaN patterns at allocation
+    bool no_head_fold = false;     // HH_NO_HEAD_FOLD=1: init_heatmaps_head writes its output into the concat buffer, the transposed conv reads it
     bool poison_lds = false;       // HH_POISON_LDS=1 (tests): every CU's LDS filled with NaN patterns in front of every launch
     unsigned debug_skip = 0;       // HH_DEBUG_SKIP=cat[,cat..] (measurement only, results are WRONG): launches of these categories are not
                                    // issued -- how much of the forward's wall time hangs on a kernel family (tools/probes/skip_sensitivity.sh)

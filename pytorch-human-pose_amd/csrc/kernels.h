@@ -162,10 +162,6 @@ hipError_t bbpc_init();
 bool bbpc_supported(const BBParams &p);
 hipError_t bbpc_launch(BBParams p, int num_cus, hipStream_t s);
 // the same block for the 64-channel branch (basicblock_fused_c64.hip): weights packed KS=3,S=1,KC=32,NT=2 ([chunk][tap][4][64][8])
-#define HH_CFG_BB128_FUSED 104
-// ... and for the 128-channel branch (basicblock_fused_c128.hip): weights packed KS=3,S=1,KC=16,COUT_T=128 ([chunk][tap][2][128][8])
-hipError_t bb128_fused_init();
-hipError_t bb128_fused_launch(BBParams p, int num_cus, hipStream_t s);
 #define HH_CFG_BB64_FUSED 103
 hipError_t bb64_fused_init();
 hipError_t bb64_fused_launch(BBParams p, int num_cus, hipStream_t s);
