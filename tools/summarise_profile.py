@@ -130,6 +130,9 @@ if fp8_serial:
         if m:
             ks, s_, kc, nt, pt, tw = m.groups()
             fp8_traffic[f"conv_fp8_kernel<KS={ks},S={s_},KC={kc},NT={nt},WC=1,PT={pt},TW={tw}>"] = round(2 * ffetch.get(n, 0.0) + fwrite.get(n, 0.0), -5)
+        elif "bb_fp8_kernel" in n:  # (the bench names the fused e4m3 block without its template arguments: the larger of its instantiations)
+            key = "bb_fp8_kernel (fused e4m3 BasicBlock: conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU)"
+            fp8_traffic[key] = max(fp8_traffic.get(key, 0.0), round(2 * ffetch.get(n, 0.0) + fwrite.get(n, 0.0), -5))
 train_csv = os.path.join(prof, f"{tag}_train_step_kernel_stats.csv")
 if os.path.exists(train_csv):  # kept from `rocprofv3 --kernel-trace --stats -- python3 tools/train_bench.py 32 5` (7 steps traced)
     trows = list(csv.DictReader(open(train_csv)))
