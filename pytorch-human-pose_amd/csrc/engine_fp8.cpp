@@ -168,6 +168,15 @@ int hh_net::resolve_scales()
         if (op.out >= 0 && tensors[op.out].shared_scale && (op.kind == OP_CONV || op.kind == OP_UPADD)) shared[op.out] = std::max(shared[op.out], amax[i]);
     }
     std::vector<float> cur(tensors.size(), 1.f);
+    // d_mult = s_in * w_scale lives with the LAYER while s_in belongs to the OP: sound only while no layer is launched by two ops
+    std::vector<int> layer_ops(layers.size(), 0);
+    for (const Op &op : ops)
+        if ((op.kind == OP_CONV && !op.hi) || op.kind == OP_BB) {
+            if (++layer_ops[op.layer] > 1 || (op.kind == OP_BB && ++layer_ops[op.layer2] > 1)) {
+                hh_set_error("fp8 plan: a conv layer is launched by more than one op (per-layer d_mult would be ambiguous)");
+                return 1;
+            }
+        }
     for (size_t i = 0; i < ops.size(); ++i) {
         Op &op = ops[i];
         switch (op.kind) {

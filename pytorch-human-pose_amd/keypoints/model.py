@@ -148,7 +148,11 @@ class KeypointsModule:
             metrics[f"push_{i}_loss"] = push_losses[i].item()
             metrics[f"pull_{i}_loss"] = pull_losses[i].item()
         stages_hms, tags = [h.detach().float() for h in stages_hms], tags.detach().float()
-        parser = MPPEHeatmapParser(stages_hms[0].shape[1], 20, 0.1, 1.0)
+        # one parser (= one device workspace) for the life of the module, not one per step
+        K = stages_hms[0].shape[1]
+        parser = getattr(self, "_val_parser", None)
+        if parser is None or parser.num_kpts != K:
+            parser = self._val_parser = MPPEHeatmapParser(K, 20, 0.1, 1.0)
         cpu_images = images.detach().cpu()
         results = [KeypointsResult(cpu_images[i], [h[i:i + 1] for h in stages_hms], tags[i:i + 1], COCO_LIMBS, 20, 0.1, 1.0, parser=parser)
                    for i in range(len(cpu_images))]

@@ -315,3 +315,18 @@ def test_coco_result_packing_equals_the_reference_run():
     assert json.loads(json.dumps(got)) == want
     assert [r["image_id"] for r in got][:4] == [139, 139, 139, 785] and got[-1]["image_id"] == 100000000001
     assert all(isinstance(r["score"], float) and len(r["keypoints"]) == 51 and r["keypoints"][2::3] == [1.0] * 17 for r in got)
+
+
+def test_hand_counted_lds_waits_have_no_scalar_load_in_flight():
+    """basicblock_fused_pc.hip / stem_fused.hip wait for their asm `ds_read_b128` fragments with `s_waitcnt lgkmcnt(N > 0)`, which is
+    only sound while no scalar memory load (same counter, out-of-order return) is in flight at those waits.  The source keeps
+    the kernel-argument reads outside the tile loops; tools/check_lds_wait_isa.py verifies on the emitted gfx950 assembly that the
+    compiler kept them there."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0]
+    out = subprocess.run([_sys.executable, os.path.join(root, "tools", "check_lds_wait_isa.py"),
+                          os.path.join(root, PKG, "csrc", "basicblock_fused_pc.hip"), os.path.join(root, PKG, "csrc", "stem_fused.hip")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "222 partial" in out.stdout or "partial lgkmcnt waits, 0 with" in out.stdout
