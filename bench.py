@@ -47,7 +47,8 @@ CONFIGS = {
     "bf16_w48_b64_640": dict(C=48, dtype="bf16", batch=64, size=640, peak=MFMA_BF16_DENSE_PEAK_TFLOPS,
                              metric="images/sec (fwd+decode) HigherHRNet-W48 bf16 640px", name="HigherHRNet-W48 inference bf16"),
     "fp8_w48_b64_640": dict(C=48, dtype="fp8", batch=64, size=640, peak=MFMA_FP8_DENSE_PEAK_TFLOPS,
-                            metric="images/sec (fwd+decode) HigherHRNet-W48 fp8 640px", name="HigherHRNet-W48 inference fp8 (e4m3 MFMA conv path)"),
+                            metric="images/sec (fwd+decode) HigherHRNet-W48 fp8 640px", name="HigherHRNet-W48 inference fp8 (e4m3 MFMA conv path, EXPERIMENTAL: outputs 5-8 % rms from fp32 on seeded "
+                                 "nets, no trained checkpoint to measure AP with; the decode half runs on constructed maps)"),
 }
 
 
