@@ -31,7 +31,6 @@ PlanSwitches PlanSwitches::from_env()
     s.poison_ws = on("HH_POISON_WS");
     s.poison_lds = on("HH_POISON_LDS");
     s.no_head_fold = on("HH_NO_HEAD_FOLD");
-    if (const char *lg = getenv("HH_LANE_GRAPH")) s.lane_graph = atoi(lg) ? 1 : 0;
     if (const char *sk = getenv("HH_DEBUG_SKIP")) {
         static const struct { const char *name; unsigned bit; } cats[] = {{"s2big", SK_S2BIG}, {"s2", SK_S2}, {"upadd", SK_UPADD}, {"c1x1", SK_C1X1},
             {"c256", SK_C256}, {"c128", SK_C128}, {"junc", SK_JUNC}, {"bb32", SK_BB32}, {"bb64", SK_BB64}, {"stem", SK_STEM}, {"deconv", SK_DECONV},
@@ -883,12 +882,6 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         }
     }
     hipStream_t L[4] = {s0, multi ? lane_streams[1] : s0, multi ? lane_streams[2] : s0, multi ? lane_streams[3] : s0};
-    const bool building = gb != nullptr;  // build_lane_graph(): every launch goes to the capture stream, edges become node dependencies
-    if (building) {
-        if (!multi) { hh_set_error("build_lane_graph: the multi-lane plan is off"); return 1; }
-        for (int l = 0; l < 4; ++l) L[l] = gb->cap;
-    }
-    auto frontier = [&](int m) { std::vector<hipGraphNode_t> f = gb->last[m]; f.insert(f.end(), gb->pend[m].begin(), gb->pend[m].end()); return f; };
     lane_events_used = 0;
     auto next_event = [&](hipEvent_t *e) -> int {
         if (lane_events_used == lane_events.size()) {
@@ -915,37 +908,6 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
     hipEvent_t mark_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     for (const Op &op : ops) {
         hipStream_t s = L[op.lane];
-        if (building) {
-            const bool edge = op.kind == OP_JOIN || op.kind == OP_MARK || op.kind == OP_WAITL || op.kind == OP_DEP;
-            if (edge || op.kind == OP_TAP || gb->open_lane != op.lane)
-                if (graph_close_segment()) return 1;
-            if (edge) {
-                const int nrec = op.nlanes < lanes_open ? op.nlanes : lanes_open;
-                if (op.kind == OP_JOIN) {
-                    std::vector<hipGraphNode_t> F[4];
-                    for (int m = 0; m < nrec; ++m) F[m] = frontier(m);
-                    for (int l = 0; l < op.nlanes; ++l)
-                        for (int m = 0; m < nrec; ++m)
-                            if (m != l) gb->pend[l].insert(gb->pend[l].end(), F[m].begin(), F[m].end());
-                    if (op.nlanes > lanes_open) lanes_open = op.nlanes;
-                } else if (op.kind == OP_MARK) {
-                    for (int m = 0; m < 4; ++m) gb->mark[m].clear();
-                    for (int m = 0; m < nrec; ++m) gb->mark[m] = frontier(m);
-                    if (op.nlanes > lanes_open) lanes_open = op.nlanes;
-                } else if (op.kind == OP_WAITL) {
-                    gb->pend[op.lane].insert(gb->pend[op.lane].end(), gb->mark[op.dep_from].begin(), gb->mark[op.dep_from].end());
-                } else {
-                    const std::vector<hipGraphNode_t> f = frontier(op.dep_from);
-                    gb->pend[op.lane].insert(gb->pend[op.lane].end(), f.begin(), f.end());
-                }
-                continue;
-            }
-            if (op.kind == OP_TAP) continue;
-            if (gb->open_lane < 0) {
-                HH_CHECK_HIP(hipStreamBeginCapture(gb->cap, hipStreamCaptureModeThreadLocal));
-                gb->open_lane = op.lane;
-            }
-        }
         if (sw.debug_skip) {  // measurement only: the outputs are wrong
             unsigned cat = 0;
             if (op.kind == OP_UPADD) cat = SK_UPADD;
@@ -1279,7 +1241,6 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         }
         }
     }
-    if (building) return graph_close_segment();  // (the graph is complete when all its nodes are: no closing edges)
     if (multi)
         for (int l = 1; l < lanes_open; ++l) {  // close the fork: the caller's stream waits for every lane
             hipEvent_t e;
@@ -1300,29 +1261,18 @@ int hh_net::forward(const float *images, int B, int H, int W, float *o1, float *
     // hipGraph capture of the multi-stream fork/join segfaults inside the ROCm 7.2 runtime on this plan, so the
     // multi-lane mode always launches eagerly (at B=32 eager and graph replay time identically); graphs remain
     // available for single-lane execution (hh_set_multi_lane(net, 0)), which is what small batches want.
-    // Multi-lane plan: replayed from an explicit hipGraph (build_lane_graph) where that pays -- small batches, where the forward is
-    // a chain of ~260 launches of a few microseconds each and the host's ~1.4 ms of enqueue work per forward shows --, eager at
-    // large batches (HH_LANE_GRAPH=0 / 1 forces either).
-    const bool lane_graph = multi_lane && dtype != 2 && (sw.lane_graph == 1 || (sw.lane_graph < 0 && (long)B * H * W <= 8L * 512 * 512));
-    if (!use_graph || s == nullptr || taps_enabled || prof_enabled || sw.poison_lds || sw.debug_skip || (multi_lane && !lane_graph))
+    // The multi-lane plan always launches eagerly.  Stream capture of its fork / join pattern segfaults inside the ROCm 7.2 runtime,
+    // and the explicit graph built in round 3 (kernel nodes re-added one by one, the plan's edges as node dependencies: git log,
+    // profiles/r03_ab.md) replays bit-equal but ~4 ms SLOWER per forward than the eager launches at every batch size (1.55 vs
+    // 5.6 ms at batch 1): the runtime's graph executor costs ~15 us per node.  Graphs remain for single-lane execution
+    // (hh_set_multi_lane(net, 0)), where eager and replay time alike.
+    if (!use_graph || s == nullptr || taps_enabled || prof_enabled || sw.poison_lds || sw.debug_skip || multi_lane)
         return enqueue(images, B, H, W, o1, o2, s);
     for (auto &g : graphs)
         if (g.images == images && g.o1 == o1 && g.o2 == o2 && g.B == B && g.H == H && g.W == W) {
             HH_CHECK_HIP(hipGraphLaunch(g.exec, s));
             return 0;
         }
-    if (multi_lane) {
-        GraphEntry g{images, o1, o2, B, H, W, nullptr};
-        if (build_lane_graph(images, B, H, W, o1, o2, &g.exec)) return 1;
-        if (graphs.size() >= 8) {
-            HH_CHECK_HIP(hipStreamSynchronize(s));
-            hipGraphExecDestroy(graphs.front().exec);
-            graphs.erase(graphs.begin());
-        }
-        graphs.push_back(g);
-        HH_CHECK_HIP(hipGraphLaunch(g.exec, s));
-        return 0;
-    }
     hipGraph_t graph;
     HH_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = enqueue(images, B, H, W, o1, o2, s);
@@ -1340,67 +1290,6 @@ int hh_net::forward(const float *images, int B, int H, int W, float *o1, float *
     graphs.push_back(g);
     HH_CHECK_HIP(hipGraphLaunch(g.exec, s));
     return 0;
-}
-
-// One captured run of launches on one lane -> kernel nodes of the main graph (see GraphBuild).
-int hh_net::graph_close_segment()
-{
-    GraphBuild &g = *gb;
-    if (g.open_lane < 0) return 0;
-    const int l = g.open_lane;
-    g.open_lane = -1;
-    hipGraph_t seg = nullptr;
-    HH_CHECK_HIP(hipStreamEndCapture(g.cap, &seg));
-    size_t n = 0;
-    HH_CHECK_HIP(hipGraphGetNodes(seg, nullptr, &n));
-    if (n) {
-        size_t nroot = 0;
-        HH_CHECK_HIP(hipGraphGetRootNodes(seg, nullptr, &nroot));
-        if (nroot != 1) { hipGraphDestroy(seg); hh_set_error("build_lane_graph: a captured segment is not a chain"); return 1; }
-        hipGraphNode_t cur = nullptr;
-        HH_CHECK_HIP(hipGraphGetRootNodes(seg, &cur, &nroot));
-        std::vector<hipGraphNode_t> deps = g.last[l];
-        deps.insert(deps.end(), g.pend[l].begin(), g.pend[l].end());
-        for (size_t i = 0; i < n; ++i) {
-            hipGraphNodeType type;
-            HH_CHECK_HIP(hipGraphNodeGetType(cur, &type));
-            if (type != hipGraphNodeTypeKernel) { hipGraphDestroy(seg); hh_set_error("build_lane_graph: a segment holds a node that is not a kernel"); return 1; }
-            hipKernelNodeParams kp;
-            HH_CHECK_HIP(hipGraphKernelNodeGetParams(cur, &kp));
-            hipGraphNode_t nn = nullptr;
-            HH_CHECK_HIP(hipGraphAddKernelNode(&nn, g.main, deps.empty() ? nullptr : deps.data(), deps.size(), &kp));
-            ++g.nodes;
-            deps.assign(1, nn);
-            if (i + 1 < n) {
-                size_t nd = 0;
-                HH_CHECK_HIP(hipGraphNodeGetDependentNodes(cur, nullptr, &nd));
-                if (nd != 1) { hipGraphDestroy(seg); hh_set_error("build_lane_graph: a captured segment is not a chain"); return 1; }
-                HH_CHECK_HIP(hipGraphNodeGetDependentNodes(cur, &cur, &nd));
-            }
-        }
-        g.last[l] = deps;
-        g.pend[l].clear();
-    }
-    HH_CHECK_HIP(hipGraphDestroy(seg));
-    return 0;
-}
-
-int hh_net::build_lane_graph(const float *images, int B, int H, int W, float *o1, float *o2, hipGraphExec_t *exec)
-{
-    GraphBuild g;
-    HH_CHECK_HIP(hipGraphCreate(&g.main, 0));
-    HH_CHECK_HIP(hipStreamCreateWithFlags(&g.cap, hipStreamNonBlocking));
-    gb = &g;
-    int rc = enqueue(images, B, H, W, o1, o2, g.cap);
-    gb = nullptr;
-    if (g.open_lane >= 0) { hipGraph_t junk = nullptr; hipStreamEndCapture(g.cap, &junk); if (junk) hipGraphDestroy(junk); }
-    if (!rc) {
-        hipError_t e = hipGraphInstantiate(exec, g.main, nullptr, nullptr, 0);
-        if (e != hipSuccess) { hh_set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); rc = 1; }
-    }
-    hipGraphDestroy(g.main);
-    hipStreamDestroy(g.cap);
-    return rc;
 }
 
 // Static hazard check of the multi-lane plan: replays the fork/join/dep edges of enqueue() with vector clocks (one

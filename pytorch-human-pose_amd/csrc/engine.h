@@ -136,8 +136,6 @@ struct PlanSwitches {
     bool full_join = false;        // HH_FULL_JOIN=1: all-to-all joins of the branch lanes instead of per-source waits
     bool no_fusion_merge = false;  // HH_NO_FUSION_MERGE=1: one launch per summed stride-2 conv of a fusion layer
     bool poison_ws = false;        // HH_POISON_WS=1 (tests): workspace filled with NaN patterns at allocation
-    int lane_graph = -1;           // HH_LANE_GRAPH=0: multi-lane forwards always eager; 1: always replayed from an explicit hipGraph (when the
-                                   // caller allows graphs); default (-1): graph for small batches only (see hh_net::forward)
     bool no_head_fold = false;     // HH_NO_HEAD_FOLD=1: init_heatmaps_head writes its output into the concat buffer, the transposed conv reads it
     bool poison_lds = false;       // HH_POISON_LDS=1 (tests): every CU's LDS filled with NaN patterns in front of every launch
     unsigned debug_skip = 0;       // HH_DEBUG_SKIP=cat[,cat..] (measurement only, results are WRONG): launches of these categories are not
@@ -149,20 +147,6 @@ struct PlanSwitches {
 
 enum SkipCat { SK_S2BIG = 1, SK_S2 = 2, SK_UPADD = 4, SK_C1X1 = 8, SK_C256 = 16, SK_C128 = 32, SK_JUNC = 64, SK_BB32 = 128, SK_BB64 = 256,
                SK_STEM = 512, SK_DECONV = 1024, SK_HEAD = 2048, SK_TRANS0 = 4096 };
-
-// Explicit hipGraph of the multi-lane plan (hh_net::build_lane_graph): the plan is walked once with every launch going to one
-// capture stream; each run of launches on one lane is captured on its own (single-stream capture, the only kind that works on this
-// runtime), its kernel nodes are re-added to the main graph with hipGraphAddKernelNode, and the plan's JOIN / MARK / WAITL / DEP
-// edges become node dependencies.  A lane's position is the set of nodes everything later on that lane must follow.
-struct GraphBuild {
-    hipGraph_t main = nullptr;
-    hipStream_t cap = nullptr;
-    int open_lane = -1;                        // lane of the segment being captured (-1: none)
-    std::vector<hipGraphNode_t> last[4];       // the lane's last kernel node (empty: nothing launched on it yet)
-    std::vector<hipGraphNode_t> pend[4];       // further nodes its next launch has to follow (waits taken since)
-    std::vector<hipGraphNode_t> mark[4];       // the lane's position at the last OP_MARK
-    int nodes = 0;
-};
 
 struct hh_net {
     int K, C, dtype;
@@ -214,9 +198,6 @@ struct hh_net {
     int finalize();
     int reserve(int B, int H, int W);
     int enqueue(const float *images, int B, int H, int W, float *o1, float *o2, hipStream_t s);
-    GraphBuild *gb = nullptr;  // non-NULL while build_lane_graph() walks the plan
-    int graph_close_segment();
-    int build_lane_graph(const float *images, int B, int H, int W, float *o1, float *o2, hipGraphExec_t *exec);
     int forward(const float *images, int B, int H, int W, float *o1, float *o2, int use_graph, hipStream_t s);
     double flops(int B, int H, int W) const;
     int finalize_fp8();
