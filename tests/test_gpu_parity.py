@@ -909,6 +909,44 @@ def test_running_statistics_match_torch_batchnorm(pkg):
         assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == 3
 
 
+def test_train_step_batch8_matches_reference_autograd_tightly(pkg):
+    """The same end-to-end comparison at batch 8 (tests/golden/train_step_b8.npz: the reference net in .train() mode + torch
+    autograd): with 8 images the lowest-resolution branch normalises over 128 samples per channel instead of 32, the batch
+    statistics stop moving with bf16 rounding, and the tolerance is what bf16 activations through ~110 conv + BN layers leave:
+    loss within 0.3 %, outputs within 4 % of max, the gradient norm of every one of the 907 parameters within 10 % (median within
+    2 %) and its direction against the fp32 oracle's full gradient at cosine > 0.92 (median > 0.98)."""
+    g = np.load(os.path.join(GOLDEN, "train_step_b8.npz"))
+    K = 17
+    net = pkg.HigherHRNet(K, 32)
+    sd = {k: torch.from_numpy(pkg.synth.synth_param(k, v.shape, 5)) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    x = torch.from_numpy(pkg.synth.synth_images(8, 128, 128, seed=1))
+    hms, tags = net(x.to(DEV))
+    loss = (hms[0] ** 2).mean() + (hms[1] ** 2).mean() + (tags ** 2).mean()
+    loss.backward()
+    dl = abs(loss.item() - float(g["loss"])) / float(g["loss"])
+    eo = []
+    for name, t in (("hm0", hms[0]), ("hm1", hms[1]), ("tags", tags)):
+        a = t.detach().float().cpu().numpy().ravel()
+        eo.append(float(np.abs(a[g[f"{name}.idx"]] - g[f"{name}.val"]).max() / float(g[f"{name}.absmax"])))
+    names = [str(n) for n in g["grad.names"]]
+    params = dict(net.named_parameters())
+    ratios = np.array([params[n].grad.double().norm().item() / max(g["grad.norms"][i], 1e-30) for i, n in enumerate(names)])
+    osd = {k: (v.clone().float().requires_grad_() if k in params else v.clone()) for k, v in sd.items()}
+    oh, ot = ofw.higher_hrnet(x, osd, K, train=True)
+    ((oh[0] ** 2).mean() + (oh[1] ** 2).mean() + (ot ** 2).mean()).backward()
+    cos = np.array([float(torch.dot(params[n].grad.float().cpu().flatten(), osd[n].grad.flatten()) /
+                          (params[n].grad.float().cpu().norm() * osd[n].grad.norm() + 1e-30)) for n in names])
+    print(f"train step B=8: loss rel {dl:.4f}, outputs max/absmax {eo}, grad norm ratio [{ratios.min():.3f}, {ratios.max():.3f}] median {np.median(ratios):.3f}, "
+          f"cosine min {cos.min():.4f} (param {names[int(cos.argmin())]}) median {np.median(cos):.4f}")
+    assert dl < 3e-3 and max(eo) < 4e-2, (dl, eo)
+    assert np.all((ratios > 0.90) & (ratios < 1.10)) and abs(np.median(ratios) - 1) < 0.02, (ratios.min(), ratios.max(), np.median(ratios))
+    # measured: min 0.936 (the stem's and stage 0's weights: their gradients have crossed all ~110 layers backwards in bf16), median 0.987;
+    # at batch 2 the same quantities are 0.85 / 0.95 -- the difference is the batch statistics, not the kernels
+    assert cos.min() > 0.92 and np.median(cos) > 0.98, (cos.min(), np.median(cos))
+
+
 def test_train_step_matches_reference_autograd(pkg):
     """HigherHRNet in .train() mode on the HIP training kernels (bf16 activations, batch-statistics BatchNorm, fp32 parameter
     gradients) against (i) the reference net in .train() mode + torch autograd (tests/golden/train_step.npz) and (ii) the

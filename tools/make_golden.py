@@ -311,13 +311,15 @@ def loss_fixtures():
     json.dump({"cases": [list(c) for c in LOSS_CASES]}, open(os.path.join(OUT, "loss_meta.json"), "w"), indent=1)
 
 
-def train_fixture():
+def train_fixture(batch=2, fname="train_step.npz"):
     """The reference HigherHRNet in .train() mode (batch-statistics BatchNorm): forward on a seeded batch, the scalar
-    mean(hm0^2) + mean(hm1^2) + mean(tags^2), torch autograd gradients of it, and the running statistics after the step."""
+    mean(hm0^2) + mean(hm1^2) + mean(tags^2), torch autograd gradients of it, and the running statistics after the step.
+    batch = 8 (train_step_b8.npz): the 256-channel branch then normalises over 128 samples per channel instead of 32, so the
+    batch statistics themselves no longer move with bf16 rounding and the end-to-end comparison can be tight."""
     net = HigherHRNet(17, 32)
     load_synth(net, 5)
     net.train()
-    x = torch.from_numpy(synth.synth_images(2, 128, 128, seed=1))
+    x = torch.from_numpy(synth.synth_images(batch, 128, 128, seed=1))
     hms, tags = net(x)
     loss = (hms[0] ** 2).mean() + (hms[1] ** 2).mean() + (tags ** 2).mean()
     loss.backward()
@@ -340,8 +342,8 @@ def train_fixture():
     for k in ("backbone.bn1.running_mean", "backbone.bn1.running_var", "deconv_layers.0.deconv.1.running_mean",
               "backbone.stages.3.blocks.4.scales_blocks.3.3.bn2.running_var"):
         out["stat." + k] = sd[k].numpy()
-    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
-    print("train fixture: loss", out["loss"], "params", len(names))
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print("train fixture", fname, ": loss", out["loss"], "params", len(names))
 
 
 def train_autocast_fixture():
@@ -503,6 +505,8 @@ if __name__ == "__main__":
         train_autocast_fixture()
     if "train" in which:
         train_fixture()
+    if "train_b8" in which:
+        train_fixture(8, "train_step_b8.npz")
     if "loss" in which:
         loss_fixtures()
     if "munkres" in which:
