@@ -312,9 +312,12 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     float (*nv)[TS + 1] = rm;  // reuse (rare path below): NMS'ed values of the tile
     NMS_STAMP(4);
     {  // compact the positive peaks: per-thread counts -> wave prefix sum -> one LDS atomic per wave for the base slot
+        // (tile skipping on: only peaks above det_thr can ever matter -- match_by_tag filters `score > det_thr`, grouping.py:98-102 --,
+        // so the background's local maxima, a hundred per tile on noisy maps, are not compacted, ranked or written)
+        const float pos_thr = skip_thr > 0.f ? skip_thr : 0.f;
         unsigned pm = 0;
 #pragma unroll
-        for (int j = 0; j < SL; ++j) pm |= (j < nin && vals[j] > 0.f) ? (1u << j) : 0u;
+        for (int j = 0; j < SL; ++j) pm |= (j < nin && vals[j] > pos_thr) ? (1u << j) : 0u;
         const int cnt = __popc(pm);
         int incl = cnt;
 #pragma unroll
@@ -354,6 +357,10 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             }
         }
         start = npos < M ? npos : M;
+        if (skip_thr >= 0.f) {  // tile skipping on: the rest of the list stays empty, as a skipped tile's whole list does
+            if (tid >= start && tid < M) cand_key[obase + tid] = 0ull;
+            return;
+        }
         // zero-valued pixels in index order, one tile row per ballot.  The first SL rows are wave 0's own pixels (registers);
         // they almost always hold the M - npos zeros still wanted.
         if (start < M && tid < 64) {
@@ -496,10 +503,36 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const DecodeSrc src, in
     const float *vals = cand_val + ((size_t)b * src.K + k) * N;
     const size_t obase = ((size_t)b * src.K + k) * M;
     const bool staged = N <= NST;  // else the rounds scan (and consume) the global list
+    __shared__ u64 ckey[256];
+    __shared__ int cpos[256];
+    __shared__ int ccnt;
+    if (tid == 0) ccnt = 0;
     if (staged) {
         for (int i = tid; i < N; i += 256) skeys[i] = gkeys[i];
         __syncthreads();
+        // With sub-threshold tiles skipped and the tiles' lists cut at det_thr (nms_tile_topk_kernel) a map holds a handful of
+        // non-empty keys among its ntiles * M slots: compact them, rank each against the others (keys are unique), done -- two
+        // barriers instead of M rounds of workgroup arg-max.  More than 256 of them: the rounds below.
+        for (int i = tid; i < N; i += 256) {
+            const u64 kk = skeys[i];
+            if (kk != 0ull) {
+                const int slot = atomicAdd(&ccnt, 1);
+                if (slot < 256) { ckey[slot] = kk; cpos[slot] = i; }
+            }
+        }
+        __syncthreads();
     }
+    const int nnz = staged ? ccnt : 257;
+    if (nnz <= 256) {
+        if (tid < M) { win_key[tid] = 0ull; win_pos[tid] = -1; }
+        __syncthreads();
+        if (tid < nnz) {
+            const u64 me = ckey[tid];
+            int rank = 0;
+            for (int i = 0; i < nnz; ++i) rank += ckey[i] > me;
+            if (rank < M) { win_key[rank] = me; win_pos[rank] = cpos[tid]; }
+        }
+    } else
     for (int r = 0; r < M; ++r) {  // M rounds of workgroup-wide arg-max; one barrier per round (the exchange buffer alternates)
         u64 best = 0ull;
         int pos = -1;
