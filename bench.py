@@ -323,7 +323,7 @@ def main():
     if args.single_lane:
         lib.hh_set_multi_lane(net._h, 0)
     # Highest-priority streams: dependent launches on a high-priority queue follow each other faster on this stack (forward
-    # alone 5.25 -> 4.93 ms, step 5.85 -> 5.53 ms; measured with tools/probes/ab_env2.sh).  HH_STREAM_PRIORITY=0 for A/B runs.
+    # alone 5.25 -> 4.93 ms, step 5.85 -> 5.53 ms; round-2 A/B).  HH_STREAM_PRIORITY=0 for A/B runs.
     prio = int(os.environ.get("HH_STREAM_PRIORITY", str(torch.cuda.Stream.priority_range()[1])))
     side = torch.cuda.Stream(dev, priority=prio)   # forward stream (the engine forks its branch lanes from it)
     side2 = torch.cuda.Stream(dev, priority=prio)  # decode stream
