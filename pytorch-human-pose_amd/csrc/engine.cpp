@@ -31,7 +31,6 @@ PlanSwitches PlanSwitches::from_env()
     s.poison_ws = on("HH_POISON_WS");
     s.poison_lds = on("HH_POISON_LDS");
     s.no_head_fold = on("HH_NO_HEAD_FOLD");
-    s.no_fuse_up = on("HH_NO_FUSE_UP");
     if (const char *sk = getenv("HH_DEBUG_SKIP")) {
         static const struct { const char *name; unsigned bit; } cats[] = {{"s2big", SK_S2BIG}, {"s2", SK_S2}, {"upadd", SK_UPADD}, {"c1x1", SK_C1X1},
             {"c256", SK_C256}, {"c128", SK_C128}, {"junc", SK_JUNC}, {"bb32", SK_BB32}, {"bb64", SK_BB64}, {"stem", SK_STEM}, {"deconv", SK_DECONV},
@@ -396,26 +395,12 @@ struct Builder {
                     auto need_all = [&]() { for (int j = 0; j < nsc; ++j) need(j); };
                     Op up;
                     up.kind = OP_UPADD; up.in = x[i]; up.out = OUT; up.C = w[i]; up.relu = (i == 0); up.lane = lane;
-                    // bf16: the 1x1 convs of the lower branches and the upsample-add as ONE launch (fusion_up.hip, bit-identical to the
-                    // separate launches; HH_NO_FUSE_UP=1 or a weight set too large for its LDS: layer by layer)
-                    bool fuse_up = n.dtype != 2 && !n.sw.no_fuse_up && i + 1 < nsc;
-                    if (fuse_up) {
-                        int cinp[3], coutp[3], shf[3], ns = 0;
-                        for (int j = i + 1; j < nsc; ++j, ++ns) { cinp[ns] = round_up(w[j], 32); coutp[ns] = round_up(w[i], 32); shf[ns] = j - i; }
-                        fuse_up = fusion_up_fits(w[i], ns, cinp, coutp, shf);
-                    }
-                    if (fuse_up) up.kind = OP_FUSEUP;
                     for (int j = i + 1; j < nsc; ++j) {  // low -> high: 1x1 conv + BN at low res
                         const std::string lp = fp + ".scales_fusion_layers." + std::to_string(i) + "." + std::to_string(j);
+                        const int u = T(w[i], 2 + j);
                         need(j);
-                        if (fuse_up) {
-                            up.up[up.nup] = x[j]; up.up_layer[up.nup] = L(lp + ".0", lp + ".1", w[j], w[i], 1, 1);
-                        } else {
-                            const int u = T(w[i], 2 + j);
-                            cb(lp, "0", "1", w[j], w[i], 1, 1, x[j], u, 0);
-                            up.up[up.nup] = u;
-                        }
-                        up.up_shift[up.nup] = j - i; ++up.nup;
+                        cb(lp, "0", "1", w[j], w[i], 1, 1, x[j], u, 0);
+                        up.up[up.nup] = u; up.up_shift[up.nup] = j - i; ++up.nup;
                     }
                     if (up.nup) { need_all(); n.ops.push_back(up); cur = OUT; }
                     // high -> low, two or more sources (bf16): the LAST stride-2 conv of every chain reads at the resolution above the
@@ -925,7 +910,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         hipStream_t s = L[op.lane];
         if (sw.debug_skip) {  // measurement only: the outputs are wrong
             unsigned cat = 0;
-            if (op.kind == OP_UPADD || op.kind == OP_FUSEUP) cat = SK_UPADD;
+            if (op.kind == OP_UPADD) cat = SK_UPADD;
             else if (op.kind == OP_JUNC) cat = SK_JUNC;
             else if (op.kind == OP_STEM) cat = SK_STEM;
             else if (op.kind == OP_BB) cat = layers[op.layer].cout == 32 ? SK_BB32 : layers[op.layer].cout == 64 ? SK_BB64 : 0;
@@ -1056,22 +1041,6 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             p.out = o.ptr; p.out_cs = o.C; p.out_coff = 0;
             p.B = B; p.H = H >> b.shift; p.W = W >> b.shift; p.C = op.C; p.relu = op.relu;
             HH_CHECK_HIP(launch_upadd(p, s));
-            break;
-        }
-        case OP_FUSEUP: {
-            FuseUpParams q{};
-            const TensorDesc &b = tensors[op.in], &o = tensors[op.out];
-            q.base = b.ptr; q.base_cs = b.C; q.out = o.ptr; q.out_cs = o.C;
-            q.B = B; q.H = H >> b.shift; q.W = W >> b.shift; q.C = op.C; q.relu = op.relu; q.nsrc = op.nup;
-            for (int j = 0; j < op.nup; ++j) {
-                const ConvLayer &l = layers[op.up_layer[j]];
-                const TensorDesc &t = tensors[op.up[j]];
-                q.src[j] = t.ptr; q.src_cs[j] = t.C; q.shift[j] = op.up_shift[j];
-                q.cin[j] = l.cin_pad; q.KC[j] = l.KC; q.NT[j] = l.NT;
-                q.w[j] = l.d_w; q.bias[j] = l.d_bias;
-                q.w_units[j] = l.ncg * (l.cin_pad / l.KC) * (l.KC / 8) * 32 * l.NT;
-            }
-            HH_CHECK_HIP(fusion_up_launch(q, num_cus, s));
             break;
         }
         case OP_TAP: {
@@ -1370,7 +1339,7 @@ int hh_net::check_plan(std::string *why) const
         std::vector<int> rd, wr;
         switch (op.kind) {
         case OP_CONV: rd = {op.in, op.res, op.in2, op.in3}; wr = {op.out}; break;
-        case OP_UPADD: case OP_FUSEUP: rd = {op.in, op.up[0], op.up[1], op.up[2]}; wr = {op.out}; break;
+        case OP_UPADD: rd = {op.in, op.up[0], op.up[1], op.up[2]}; wr = {op.out}; break;
         case OP_BB: rd = {op.in}; wr = {op.out}; break;
         case OP_JUNC: rd = {op.in, op.in2, op.res, op.in3}; wr = {op.out, op.out2}; break;
         case OP_STEM: wr = {op.out}; break;
@@ -1427,13 +1396,6 @@ double hh_net::flops(int B, int H, int W) const
         if (op.kind == OP_JUNC) {
             const TensorDesc &ti = tensors[op.in];
             macs += (double)(H >> ti.shift) * (W >> ti.shift) * 64.0 * 256.0 * (1 + (op.in2 >= 0 && op.layer4 < 0) + (op.layer3 >= 0));
-            continue;
-        }
-        if (op.kind == OP_FUSEUP) {
-            for (int j = 0; j < op.nup; ++j) {
-                const TensorDesc &t = tensors[op.up[j]];
-                macs += (double)(H >> t.shift) * (W >> t.shift) * (double)layers[op.up_layer[j]].cin * layers[op.up_layer[j]].cout;
-            }
             continue;
         }
         if (op.kind != OP_CONV) continue;

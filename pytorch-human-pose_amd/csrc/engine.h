@@ -70,7 +70,7 @@ struct TensorDesc {
     bool shared_scale = false;  // fp8: written in channel slices by several ops (torch.cat buffer): one scale for all of them
 };
 
-enum OpKind { OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC, OP_STEM, OP_MARK, OP_WAITL, OP_QUANT, OP_FUSEUP };
+enum OpKind { OP_CONV, OP_UPADD, OP_TAP, OP_BB, OP_JOIN, OP_AVGPOOL, OP_LINEAR, OP_DEP, OP_JUNC, OP_STEM, OP_MARK, OP_WAITL, OP_QUANT };
 
 struct Op {
     OpKind kind = OP_CONV;
@@ -86,8 +86,7 @@ struct Op {
     int f32_out = 0;  // 0 none, 1 = init_heatmaps, 2 = deconv_heatmaps
     int cout_store = -1;
     int scatter = 0;  // 1: write to (2*oy+py, 2*ox+px)
-    int up[3] = {-1, -1, -1}, up_shift[3] = {0, 0, 0}, nup = 0;  // OP_UPADD: the upsampled terms; OP_FUSEUP: the SOURCES x_j of the 1x1 convs
-    int up_layer[3] = {-1, -1, -1};                              // OP_FUSEUP: the 1x1 conv + BN of source j
+    int up[3] = {-1, -1, -1}, up_shift[3] = {0, 0, 0}, nup = 0;
     int C = 0;  // UPADD channel count / TAP channel count
     int tap = -1;
     bool res8 = false;  // fp8 handle: this conv's residual stays e4m3 (stage 0's 256-channel trunk: its 1x1 convs are HBM-bound and a bf16
@@ -137,7 +136,6 @@ struct PlanSwitches {
     bool full_join = false;        // HH_FULL_JOIN=1: all-to-all joins of the branch lanes instead of per-source waits
     bool no_fusion_merge = false;  // HH_NO_FUSION_MERGE=1: one launch per summed stride-2 conv of a fusion layer
     bool poison_ws = false;        // HH_POISON_WS=1 (tests): workspace filled with NaN patterns at allocation
-    bool no_fuse_up = false;       // HH_NO_FUSE_UP=1: a fusion output's 1x1 convs and its upsample-add as separate launches (conv_mfma + upadd_kernel)
     bool no_head_fold = false;     // HH_NO_HEAD_FOLD=1: init_heatmaps_head writes its output into the concat buffer, the transposed conv reads it
     bool poison_lds = false;       // HH_POISON_LDS=1 (tests): every CU's LDS filled with NaN patterns in front of every launch
     unsigned debug_skip = 0;       // HH_DEBUG_SKIP=cat[,cat..] (measurement only, results are WRONG): launches of these categories are not

@@ -225,19 +225,6 @@ struct UpAddParams {
 hipError_t launch_upadd(const UpAddParams &p, hipStream_t s);
 hipError_t launch_upadd_backward(const bf16_raw *dy, const bf16_raw *out, int relu, int B, int H, int W, int C, bf16_raw *g, bf16_raw *const *dup,
                                  const int *up_shift, int nup, hipStream_t s);
-// One fusion output's low -> high half in one launch (fusion_up.hip): out = [relu](base + sum_j up_{2^shift_j}(bn(conv1x1_j(src_j)))),
-// bit-identical to conv_mfma (1x1) + upadd_kernel.  Weights / shifts are the layers' conv_mfma images (KS = 1, WC = 1).
-struct FuseUpParams {
-    const bf16_raw *base; int base_cs;   // x_i [B,H,W,base_cs], channels 0..C-1
-    bf16_raw *out; int out_cs;           // [B,H,W,out_cs]
-    int B, H, W, C, relu, nsrc;
-    const bf16_raw *src[3]; int src_cs[3]; int shift[3];  // x_j [B, H >> shift, W >> shift, src_cs]
-    int cin[3], KC[3], NT[3];            // padded input width and the family of the layer's packed image
-    const bf16_raw *w[3]; const float *bias[3]; int w_units[3];  // packed weights (16-byte units), folded BN shift [coutp]
-    int w_off[3], u_off[3];              // LDS offsets, filled by the launcher
-};
-bool fusion_up_fits(int C, int nsrc, const int *cin_pad, const int *coutp, const int *shift);
-hipError_t fusion_up_launch(FuseUpParams p, int num_cus, hipStream_t s);
 // the same on e4m3 tensors: out = e4m3(act(base * base_scale + sum_j up_j * up_scale[j]) * out_inv_scale); C multiple of 16
 struct UpAddFp8Params {
     const unsigned char *base; int base_cs; float base_scale;
