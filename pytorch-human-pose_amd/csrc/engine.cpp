@@ -31,6 +31,7 @@ PlanSwitches PlanSwitches::from_env()
     s.poison_ws = on("HH_POISON_WS");
     s.poison_lds = on("HH_POISON_LDS");
     s.no_head_fold = on("HH_NO_HEAD_FOLD");
+    if (const char *fc = getenv("HH_FAT_CUS")) { s.fat_cus = s.fat_cus64 = atoi(fc); if (const char *c2 = strchr(fc, ',')) s.fat_cus64 = atoi(c2 + 1); }
     if (const char *sk = getenv("HH_DEBUG_SKIP")) {
         static const struct { const char *name; unsigned bit; } cats[] = {{"s2big", SK_S2BIG}, {"s2", SK_S2}, {"upadd", SK_UPADD}, {"c1x1", SK_C1X1},
             {"c256", SK_C256}, {"c128", SK_C128}, {"junc", SK_JUNC}, {"bb32", SK_BB32}, {"bb64", SK_BB64}, {"stem", SK_STEM}, {"deconv", SK_DECONV},
@@ -258,6 +259,7 @@ struct Builder {
                 o.in = (u & 1) ? m : x;
                 o.out = (u & 1) ? x : m;
                 o.lane = lane;
+                o.siblings = nscales > 1;  // other branches' blocks run on their lanes beside this one
                 n.ops.push_back(o);
             } else {
                 cb(up, "conv1", "bn1", C, C, 3, 1, x, m, 1);
@@ -1143,8 +1145,11 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 pr->bytes = 2.0 * B * p.H * p.W * Cb * 2 + 2.0 * 2 * 9 * Cb * Cb;
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
             }
-            if (l1.cout == 64) HH_CHECK_HIP(bb64_fused_launch(p, num_cus, s));
-            else if (!sw.bb32_tile && bbpc_supported(p)) HH_CHECK_HIP(bbpc_launch(p, num_cus, s));
+            // inside an HR module with the lanes on: half the chip per fat kernel (PlanSwitches::fat_cus); alone: all of it
+            auto budget = [&](int want) { return !(multi && op.siblings) ? num_cus : want > 0 ? (want < num_cus ? want : num_cus) : (num_cus + 1) / 2; };
+            const int fat = budget(sw.fat_cus), fat64 = budget(sw.fat_cus64);
+            if (l1.cout == 64) HH_CHECK_HIP(bb64_fused_launch(p, fat64, s));
+            else if (!sw.bb32_tile && bbpc_supported(p)) HH_CHECK_HIP(bbpc_launch(p, fat, s));
             else HH_CHECK_HIP(bb_fused_launch(p, num_cus, s));
             break;
         }

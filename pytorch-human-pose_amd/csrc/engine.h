@@ -91,6 +91,7 @@ struct Op {
     int tap = -1;
     bool res8 = false;  // fp8 handle: this conv's residual stays e4m3 (stage 0's 256-channel trunk: its 1x1 convs are HBM-bound and a bf16
                         // twin would triple their traffic; emulation: +0.3-0.5 % rms at the outputs)
+    bool siblings = false;  // OP_BB: a block of an HR module with other branches beside it (its persistent grid takes half the CUs)
     bool hi = false;  // fp8 handle: OP_CONV on the bf16 kernels over the tensors' bf16 representations; OP_QUANT: tensor `out`'s bf16 -> e4m3
     int lane = 0;     // execution lane (HIP stream): resolution branches / fusion outputs run concurrently
     int nlanes = 0;   // OP_JOIN: all-to-all barrier over lanes [0, nlanes)
@@ -136,6 +137,12 @@ struct PlanSwitches {
     bool full_join = false;        // HH_FULL_JOIN=1: all-to-all joins of the branch lanes instead of per-source waits
     bool no_fusion_merge = false;  // HH_NO_FUSION_MERGE=1: one launch per summed stride-2 conv of a fusion layer
     bool poison_ws = false;        // HH_POISON_WS=1 (tests): workspace filled with NaN patterns at allocation
+    // Persistent workgroups of the fused 32- / 64-channel blocks INSIDE an HR module (beside the other branches' lanes).  Default 0 =
+    // half the CUs each: the two fat kernels (150 KB of LDS per workgroup: a CU holds one of them and nothing else) then run side by
+    // side on disjoint halves of the chip instead of taking turns on all of it, and the thin launches of the 128- / 256-channel
+    // lanes find free CUs while either runs: forward 4.48 -> 4.39 ms, +1.5-2 % img/s (three alternations, profiles/r03_ab.md).
+    // HH_FAT_CUS=n[,m] sets them (256 = one per CU, the round-2 plan); a quarter of the chip for the 64-channel block loses 6 %.
+    int fat_cus = 0, fat_cus64 = 0;
     bool no_head_fold = false;     // HH_NO_HEAD_FOLD=1: init_heatmaps_head writes its output into the concat buffer, the transposed conv reads it
     bool poison_lds = false;       // HH_POISON_LDS=1 (tests): every CU's LDS filled with NaN patterns in front of every launch
     unsigned debug_skip = 0;       // HH_DEBUG_SKIP=cat[,cat..] (measurement only, results are WRONG): launches of these categories are not
