@@ -420,7 +420,8 @@ def main():
                 nm = names.get(c, str(c))
                 cv = (C.c_int * 7)()
                 if lib.hh_conv_config(c, cv) == 0:
-                    nm = ("conv_fp8_kernel" if c >= 1000 else "conv_mfma_kernel") + "<KS=%d,S=%d,KC=%d,NT=%d,WC=%d,PT=%d,TW=%d>" % tuple(cv)
+                    nm = ("conv_fp8_kernel" if c >= 1000 else "conv_mfma_kernel") + "<KS=%d,S=%d,KC=%d,NT=%d,WC=%d,PT=%d,TW=%d%s>" % (
+                        tuple(cv) + (",DB=1" if lib.hh_conv_config_double_buffered(c) == 1 else "",))
                 return nm
             names = {100: "bb_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32)" if os.environ.get("HH_BB32") == "tile" else
                           "bbpc_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32, producer/consumer waves)",

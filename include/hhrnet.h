@@ -110,6 +110,8 @@ int hh_profile_get(hh_net *net, int index, int *cfg, double *flops, double *byte
  * s_memtime / s_memrealtime deltas inside the kernel; 0 = not stamped.  Under load the chip holds this well below its 2.4 GHz. */
 int hh_profile_clock(hh_net *net, int index, double *ghz);
 int hh_conv_config(int cfg, int out[7]);
+/* 1 if instantiation `cfg` runs its K loop on two LDS buffers (conv_mfma.hip, DB), 0 if not, -1 for an unknown index */
+int hh_conv_config_double_buffered(int cfg);
 
 /* Kernel micro-benchmark used by tools/conv_bench.py (not on the hot path): `iters` back-to-back launches of
  * convolution instantiation `cfg` on random bf16 data, HIP-event timed; returns ms per launch.        */

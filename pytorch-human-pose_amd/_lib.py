@@ -62,6 +62,7 @@ def _sig(lib):
                            C.POINTER(C.c_char_p)]),
         "hh_profile_clock": (i32, [vp, i32, C.POINTER(C.c_double)]),
         "hh_conv_config": (i32, [i32, C.POINTER(C.c_int)]),
+        "hh_conv_config_double_buffered": (i32, [i32]),
         "hh_debug_conv_bench": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp, i32, C.POINTER(C.c_float)]),
         "hh_debug_bb_bench": (i32, [i32, i32, i32, i32, C.POINTER(C.c_float), vp]),
         "hh_debug_bb_compare": (i32, [i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -170,6 +170,13 @@ int hh_conv_config(int cfg, int out[7])
     return 0;
 }
 
+int hh_conv_config_double_buffered(int cfg)
+{
+    if (cfg >= 1000 && cfg - 1000 < conv_fp8_num_configs()) return 0;
+    if (cfg < 0 || cfg >= conv_num_configs()) return -1;
+    return conv_config(cfg).DB;
+}
+
 int hh_preprocess_u8(const unsigned char *image_hwc, int h, int w, const double dst_to_src[6], float *out_nchw, int H, int W,
                      const float mean[3], const float stdv[3], void *stream)
 {

@@ -60,7 +60,13 @@ __device__ long long g_conv_dbg[8192 * 8];
 #else
 #define CONV_STAMP(i)
 #endif
-template <int KS, int S, int KC, int NT, int WC, int PT, int TW>
+// DB = 1 (round 3): the K loop runs on TWO LDS buffers.  While the MFMAs of chunk c read buffer c & 1, the staging registers
+// that hold chunk c + 1 (loaded during chunk c - 1) are written to the other buffer between them and refilled with the loads
+// of chunk c + 2: ONE LDS-only barrier per chunk, and no phase in which the matrix pipe waits for ds_write / vmcnt -- in the
+// single-buffer form a wave's 15 ds_write_b128 per chunk (~780 clk of the CU's store path) and two barriers stand between the
+// MFMA runs, and a layer of 128 / 256 channels has one wave per SIMD, so nothing else runs meanwhile.  With KC = 16 the two
+// buffers take what one KC = 32 buffer took, so the launches keep sharing CUs with the other branch lanes.
+template <int KS, int S, int KC, int NT, int WC, int PT, int TW, int DB>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 {
     constexpr int RPT = 32 / TW;  // image rows covered by one 32-pixel MFMA column tile
@@ -76,6 +82,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     constexpr int NPL = (P_UNITS + 255) / 256, NWL = (W_UNITS + 255) / 256, NL = NPL + NWL;
     constexpr int NSTEP = KS * KS * (KC / 16);      // MFMA k-steps per chunk
     constexpr int LPS = (NL + NSTEP - 1) / NSTEP;   // prefetch loads issued per k-step
+    // DB: two buffers of (patch, weights, 16 bytes per thread that staging units without an LDS destination are written to)
+    constexpr int DUMP_OFF = PATCH_BYTES + W_UNITS * 16;
+    constexpr int BUF_BYTES = DUMP_OFF + (DB ? 256 * 16 : 0);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *lds_p = smem;
@@ -146,15 +155,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     u32x4 preg[NPL], wreg[NWL];
     // element offset of chunk `chunk` from the chunk-0 pointers (wave-uniform): its channels, and for a conv over several
     // concatenated inputs the distance to the tensor the chunk lives in
-    auto chunk_off = [&](int chunk) -> ptrdiff_t {
-        if (p.nch0 == 0 || chunk < p.nch0) return (ptrdiff_t)chunk * KC;
-        if (chunk < p.nch0 + p.nch1) return p.src_delta1 + (ptrdiff_t)(chunk - p.nch0) * KC;
-        return p.src_delta2 + (ptrdiff_t)(chunk - p.nch0 - p.nch1) * KC;
+    auto chunk_off = [&](int chunk) -> ptrdiff_t {  // (selects, no branches: it is evaluated at the head of every chunk)
+        const bool first = (p.nch0 == 0) | (chunk < p.nch0), second = chunk < p.nch0 + p.nch1;
+        const ptrdiff_t base = first ? (ptrdiff_t)0 : (second ? p.src_delta1 : p.src_delta2);
+        const int idx = first ? chunk : (second ? chunk - p.nch0 : chunk - p.nch0 - p.nch1);
+        return base + (ptrdiff_t)idx * KC;
     };
-    auto load_unit = [&](auto jc, int chunk) {
+    // (`coff` = chunk_off(chunk), evaluated ONCE per chunk by the caller: inside the select it used to sit in, its branches were
+    // emitted per unit -- three s_cbranch per patch load in the middle of the MFMA steps.  A unit outside the image reads from
+    // its image's first pixel, where the offset is as valid as anywhere; its value is never used.)
+    auto load_unit = [&](auto jc, int chunk, ptrdiff_t coff) {
         constexpr int j = decltype(jc)::value;
         if constexpr (j < NPL) {
-            preg[j] = *reinterpret_cast<const u32x4 *>(psrc[j] + ((pmask >> j) & 1u ? chunk_off(chunk) : 0));
+            preg[j] = *reinterpret_cast<const u32x4 *>(psrc[j] + coff);
         } else if constexpr (j < NL) {
             constexpr int i = j - NPL;
             const int u = tid + 256 * i;
@@ -175,7 +188,34 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
         });
     };
 
-    static_for<NL>([&](auto jc) { load_unit(jc, 0); });
+    // DB: one staging unit -> LDS buffer at byte offset `boff`.  Branch-free and without touching the data (a select on the
+    // loaded value would pull the wait for the load to wherever the compiler puts the select): every unit has a chunk-invariant
+    // destination inside a buffer -- its place in the patch / weight image, or, for a unit past the end or outside the image,
+    // the thread's dump slot; the zeros of the out-of-image units (the conv's padding) are written once, below, into both buffers.
+    int wdst[DB ? NL : 1];
+    if constexpr (DB) {
+        static_for<NL>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int u = tid + 256 * (j < NPL ? j : j - NPL);
+            if constexpr (j < NPL) wdst[j] = (pmask >> j) & 1u ? (u / C8) * PS + (u % C8) * 16 : DUMP_OFF + tid * 16;
+            else wdst[j] = u < W_UNITS ? PATCH_BYTES + u * 16 : DUMP_OFF + tid * 16;
+        });
+        static_for<NPL>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int u = tid + 256 * i;
+            if (u < P_UNITS && !((pmask >> i) & 1u)) {
+                *reinterpret_cast<u32x4 *>(smem + (u / C8) * PS + (u % C8) * 16) = u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4 *>(smem + BUF_BYTES + (u / C8) * PS + (u % C8) * 16) = u32x4{0u, 0u, 0u, 0u};
+            }
+        });
+    }
+    auto write_unit = [&](auto jc, int boff) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < NPL) *reinterpret_cast<u32x4 *>(smem + boff + wdst[j]) = preg[j];
+        else if constexpr (j < NL) *reinterpret_cast<u32x4 *>(smem + boff + wdst[j]) = wreg[j - NPL];
+    };
+
+    static_for<NL>([&](auto jc) { load_unit(jc, 0, 0); });
 
     // ---- accumulators start at bias (+ residual).  The residual is read 16 bytes per lane (couts 16m+8h..+7 of the
     //      lane's pixel) and the two half-waves exchange halves with v_permlane32_swap into the MFMA C layout.
@@ -230,8 +270,35 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     //      k-steps, LPS per step: issued in a burst they back-pressure the CU's load path (~10 B/cycle) and the MFMAs wait
     //      behind them.  `more_c` is a compile-time flag (the last chunk is a separate copy of the body): a run-time
     //      branch inside a k-step splits the scheduling region and the LDS reads / loads no longer interleave with the MFMAs.
-    auto mfma_chunk = [&](auto more_c, int chunk) {
-        constexpr bool more = decltype(more_c)::value;
+    // DB: `roff` = byte offset of the buffer this chunk reads, `woff` = of the buffer chunk + 1 is written to (when `more`);
+    // `more2`: chunk + 2 exists and is loaded into the staging registers as they are written out.  The units are dealt to the
+    // LAST steps of the chunk: a register then has (almost) a whole chunk between its load and its LDS write, in the first chunk too.
+    auto mfma_chunk = [&](auto more_c, auto more2_c, int chunk, int roff, int woff) {
+        constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
+        const int nxt = chunk + (DB ? 2 : 1);  // the chunk this one loads
+        const ptrdiff_t ncoff = (DB ? more2 : more) ? chunk_off(nxt) : 0;
+        // number of staging units among slots [q0, q0 + n) of NSLOT (DB: the units sit in the LAST NL slots)
+        constexpr auto stage_count = [](int q0, int n, int nslot) {
+            int c = 0;
+            for (int q = q0; q < q0 + n; ++q) {
+                const int j = DB ? q - (nslot - NL) : q;
+                c += j >= 0 && j < NL;
+            }
+            return c;
+        };
+        // staging work of slot q of NSLOT (slots are dealt LPX per step)
+        auto stage_slot = [&](auto qc, auto nslot_c) {
+            constexpr int q = decltype(qc)::value, NSLOT = decltype(nslot_c)::value;
+            if constexpr (DB) {
+                constexpr int j = q - (NSLOT - NL);
+                if constexpr (more && j >= 0) {
+                    write_unit(std::integral_constant<int, j>{}, woff);
+                    if constexpr (more2) load_unit(std::integral_constant<int, j>{}, nxt, ncoff);
+                }
+            } else {
+                if constexpr (more) load_unit(qc, nxt, ncoff);
+            }
+        };
         if constexpr (KS == 3 && S == 1 && TW == 32) {
             // LDS read bandwidth (8 clk per ds_read_b128, 128 B/clk/CU) is as scarce as MFMA issue here, so a pixel-row
             // fragment is read once per (kx, k-step) and used for every output row it feeds (patch row i = out row + ky):
@@ -246,12 +313,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const int unit = (((ky * 3 + kx) * C8 + kk * 2 + h) * COUT_T) + (wc * NT + nt) * 32 + r;
-                        fa[buf][ky][nt] = *reinterpret_cast<const u32x4 *>(lds_w + unit * 16);
+                        fa[buf][ky][nt] = *reinterpret_cast<const u32x4 *>(lds_w + roff + unit * 16);
                     }
             };
             auto ldb = [&](int s, int buf) {
                 const int c = s / NR, i = s % NR, kx = c / (KC / 16), kk = c % (KC / 16);
-                fb[buf] = *reinterpret_cast<const u32x4 *>(lds_p + ((wp * PT + i) * PW + dx + kx) * PS + kk * 32 + h * 16);
+                fb[buf] = *reinterpret_cast<const u32x4 *>(lds_p + roff + ((wp * PT + i) * PW + dx + kx) * PS + kk * 32 + h * 16);
             };
             lda(0, 0);
             ldb(0, 0);
@@ -262,8 +329,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
                 if constexpr (s + 1 < NS) ldb(s + 1, (s + 1) & 1);
                 if constexpr (i == 0 && c + 1 < NC) lda(c + 1, (c + 1) & 1);  // next combo's weights, a whole combo ahead
                 if constexpr (nread > 0) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);
-                if constexpr (more)
-                    static_for<LPR>([&](auto lc) { load_unit(std::integral_constant<int, s * LPR + decltype(lc)::value>{}, chunk + 1); });
+                static_for<LPR>([&](auto lc) { stage_slot(std::integral_constant<int, s * LPR + decltype(lc)::value>{}, std::integral_constant<int, NS * LPR>{}); });
+                {   // pin the step's staging between its LDS reads and its MFMAs: left alone, the scheduler gathers the loads of
+                    // several steps into one burst
+                    constexpr int nst = stage_count(s * LPR, LPR, NS * LPR);
+                    if constexpr (DB && more && nst > 0) __builtin_amdgcn_sched_group_barrier(0x200, nst, 0);
+                    if constexpr ((DB ? more2 : more) && nst > 0) __builtin_amdgcn_sched_group_barrier(0x020, nst, 0);
+                }
                 constexpr int lo = i - (PT - 1) > 0 ? i - (PT - 1) : 0, hi = i < 2 ? i : 2;  // ky range with 0 <= i - ky < PT
                 static_for<3>([&](auto kyc) {
                     constexpr int ky = decltype(kyc)::value, pt = i - ky;
@@ -283,13 +355,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int unit = ((tap * C8 + kk * 2 + h) * COUT_T) + (wc * NT + nt) * 32 + r;
-                fa[buf][nt] = *reinterpret_cast<const u32x4 *>(lds_w + unit * 16);
+                fa[buf][nt] = *reinterpret_cast<const u32x4 *>(lds_w + roff + unit * 16);
             }
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
                 const int row = (wp * PT + pt) * RPT + dy;
                 const int addr = ((row * S + ky) * PW + dx * S + kx) * PS + kk * 32 + h * 16;
-                fb[buf][pt] = *reinterpret_cast<const u32x4 *>(lds_p + addr);
+                fb[buf][pt] = *reinterpret_cast<const u32x4 *>(lds_p + roff + addr);
             }
         };
         ldf(0, 0);
@@ -300,10 +372,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
                 ldf(st + 1, (st + 1) & 1);
                 __builtin_amdgcn_sched_group_barrier(0x100, NT + PT, 0);
             }
-            if constexpr (more)
-                static_for<LPS>([&](auto lc) {
-                    load_unit(std::integral_constant<int, st * LPS + decltype(lc)::value>{}, chunk + 1);
-                });
+            static_for<LPS>([&](auto lc) { stage_slot(std::integral_constant<int, st * LPS + decltype(lc)::value>{}, std::integral_constant<int, NSTEP * LPS>{}); });
+            {
+                constexpr int nst = stage_count(st * LPS, LPS, NSTEP * LPS);
+                if constexpr (DB && more && nst > 0) __builtin_amdgcn_sched_group_barrier(0x200, nst, 0);
+                if constexpr ((DB ? more2 : more) && nst > 0) __builtin_amdgcn_sched_group_barrier(0x020, nst, 0);
+            }
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
@@ -315,18 +389,42 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
         });
     };
     CONV_STAMP(1);
-    for (int chunk = 0; chunk + 1 < nchunks; ++chunk) {
+    if constexpr (DB) {
+        // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. the loads of the chunk after next
+        auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        // (the host only picks this instantiation for layers of >= 2 chunks: no run-time case split around the loads below, which
+        // would cost a vmcnt(0) at the join -- the first MFMAs would wait for chunk 1)
+        static_for<NL>([&](auto jc) { write_unit(jc, 0); });
+        {
+            const ptrdiff_t c1 = chunk_off(1);
+            static_for<NL>([&](auto jc) { load_unit(jc, 1, c1); });
+        }
+        lds_barrier();
+        CONV_STAMP(2);
+        int chunk = 0;
+        for (; chunk + 2 < nchunks; ++chunk) {
+            mfma_chunk(std::true_type{}, std::true_type{}, chunk, (chunk & 1) * BUF_BYTES, ((chunk + 1) & 1) * BUF_BYTES);
+            lds_barrier();  // buffer (chunk + 1) & 1 is complete, and every wave is done reading buffer chunk & 1
+        }
+        mfma_chunk(std::true_type{}, std::false_type{}, chunk, (chunk & 1) * BUF_BYTES, ((chunk + 1) & 1) * BUF_BYTES);
+        lds_barrier();
+        ++chunk;
+        CONV_STAMP(4);
+        mfma_chunk(std::false_type{}, std::false_type{}, chunk, (chunk & 1) * BUF_BYTES, 0);
+    } else {
+        for (int chunk = 0; chunk + 1 < nchunks; ++chunk) {
+            write_lds();
+            __syncthreads();
+            if (chunk == 0) CONV_STAMP(2);
+            mfma_chunk(std::true_type{}, std::false_type{}, chunk, 0, 0);
+            __syncthreads();  // every wave is done reading this chunk (LDS is rewritten next)
+            if (chunk == 0) CONV_STAMP(3);
+        }
         write_lds();
         __syncthreads();
-        if (chunk == 0) CONV_STAMP(2);
-        mfma_chunk(std::true_type{}, chunk);
-        __syncthreads();  // every wave is done reading this chunk (LDS is rewritten next)
-        if (chunk == 0) CONV_STAMP(3);
+        CONV_STAMP(4);
+        mfma_chunk(std::false_type{}, std::false_type{}, nchunks - 1, 0, 0);
     }
-    write_lds();
-    __syncthreads();
-    CONV_STAMP(4);
-    mfma_chunk(std::false_type{}, nchunks - 1);
     CONV_STAMP(5);
 
     // ---- epilogue: (ReLU) -> fp32 NCHW directly, or bf16 NHWC with the half-waves paired by v_permlane32_swap so
@@ -379,32 +477,34 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 }
 
 // ---------------------------------------------------------------------------------------
-// Instantiation table. {KS, S, KC, NT, WC, PT, TW}
+// Instantiation table. {KS, S, KC, NT, WC, PT, TW, DB}
 #define CONV_CONFIGS(X)                                                                             \
-    X(3, 1, 32, 1, 1, 2, 32) /* 0: 3x3 s1, Cout tile 32,  8x32 px  (C=32 branches, deconv head) */ \
-    X(3, 1, 32, 2, 1, 2, 32) /* 1: 3x3 s1, Cout tile 64,  8x32 px  (C=64/128 branches)          */ \
-    X(3, 1, 32, 2, 1, 1, 16) /* 2: 3x3 s1, Cout tile 64,  8x16 px  (16x16 maps)                 */ \
-    X(3, 1, 16, 1, 1, 2, 32) /* 3: 3x3 s1, KC 16 fallback (Cin % 32 != 0, e.g. W48)             */ \
-    X(3, 1, 16, 2, 1, 1, 16) /* 4: same, narrow maps                                            */ \
-    X(3, 2, 16, 2, 1, 1, 32) /* 5: 3x3 s2, Cout tile 64,  4x32 px                               */ \
-    X(3, 2, 16, 1, 1, 1, 32) /* 6: 3x3 s2, Cout tile 32                                         */ \
-    X(3, 2, 16, 2, 1, 1, 16) /* 7: 3x3 s2, narrow maps                                          */ \
-    X(3, 2, 16, 1, 1, 1, 16) /* 8                                                               */ \
-    X(1, 1, 32, 2, 1, 2, 32) /* 9: 1x1, Cout tile 64, 8x32 px                                   */ \
-    X(1, 1, 32, 1, 1, 4, 32) /* 10: 1x1, Cout tile 32, 16x32 px                                 */ \
-    X(1, 1, 32, 2, 1, 1, 16) /* 11: 1x1 narrow maps                                             */ \
-    X(1, 1, 32, 1, 1, 1, 16) /* 12                                                              */ \
-    X(1, 1, 16, 2, 1, 2, 32) /* 13: 1x1 KC 16 fallback                                          */ \
-    X(1, 1, 16, 1, 1, 2, 32) /* 14                                                              */ \
-    X(2, 1, 16, 1, 1, 4, 32) /* 15: 2x2 phase of the 4x4 s2 transposed conv, Cout tile 32       */ \
-    X(2, 1, 16, 2, 1, 2, 32) /* 16: same, Cout tile 64 (W48: C=48 -> 64)                        */
+    X(3, 1, 32, 1, 1, 2, 32, 0) /* 0: 3x3 s1, Cout tile 32,  8x32 px  (C=32 branches, deconv head) */ \
+    X(3, 1, 32, 2, 1, 2, 32, 0) /* 1: 3x3 s1, Cout tile 64,  8x32 px  (C=64/128 branches)          */ \
+    X(3, 1, 32, 2, 1, 1, 16, 0) /* 2: 3x3 s1, Cout tile 64,  8x16 px  (16x16 maps)                 */ \
+    X(3, 1, 16, 1, 1, 2, 32, 0) /* 3: 3x3 s1, KC 16 fallback (Cin % 32 != 0, e.g. W48)             */ \
+    X(3, 1, 16, 2, 1, 1, 16, 0) /* 4: same, narrow maps                                            */ \
+    X(3, 2, 16, 2, 1, 1, 32, 0) /* 5: 3x3 s2, Cout tile 64,  4x32 px                               */ \
+    X(3, 2, 16, 1, 1, 1, 32, 0) /* 6: 3x3 s2, Cout tile 32                                         */ \
+    X(3, 2, 16, 2, 1, 1, 16, 0) /* 7: 3x3 s2, narrow maps                                          */ \
+    X(3, 2, 16, 1, 1, 1, 16, 0) /* 8                                                               */ \
+    X(1, 1, 32, 2, 1, 2, 32, 0) /* 9: 1x1, Cout tile 64, 8x32 px                                   */ \
+    X(1, 1, 32, 1, 1, 4, 32, 0) /* 10: 1x1, Cout tile 32, 16x32 px                                 */ \
+    X(1, 1, 32, 2, 1, 1, 16, 0) /* 11: 1x1 narrow maps                                             */ \
+    X(1, 1, 32, 1, 1, 1, 16, 0) /* 12                                                              */ \
+    X(1, 1, 16, 2, 1, 2, 32, 0) /* 13: 1x1 KC 16 fallback                                          */ \
+    X(1, 1, 16, 1, 1, 2, 32, 0) /* 14                                                              */ \
+    X(2, 1, 16, 1, 1, 4, 32, 0) /* 15: 2x2 phase of the 4x4 s2 transposed conv, Cout tile 32       */ \
+    X(2, 1, 16, 2, 1, 2, 32, 0) /* 16: same, Cout tile 64 (W48: C=48 -> 64)                        */ \
+    X(3, 1, 16, 2, 1, 2, 32, 1) /* 17: 3x3 s1, two LDS buffers (>= 128 input channels)            */ \
+    X(3, 1, 16, 2, 1, 1, 16, 1) /* 18: same, narrow maps                                          */
 
-#define CFG_ROW(ks, s, kc, nt, wc, pt, tw) {ks, s, kc, nt, wc, pt, tw},
+#define CFG_ROW(ks, s, kc, nt, wc, pt, tw, db) {ks, s, kc, nt, wc, pt, tw, db},
 static const ConvConfig g_configs[] = {CONV_CONFIGS(CFG_ROW)};
 #undef CFG_ROW
 
 typedef void (*conv_fn)(const ConvParams);
-#define CFG_FN(ks, s, kc, nt, wc, pt, tw) conv_mfma_kernel<ks, s, kc, nt, wc, pt, tw>,
+#define CFG_FN(ks, s, kc, nt, wc, pt, tw, db) conv_mfma_kernel<ks, s, kc, nt, wc, pt, tw, db>,
 static const conv_fn g_fns[] = {CONV_CONFIGS(CFG_FN)};
 #undef CFG_FN
 

@@ -28,29 +28,32 @@ struct DecodeSrc {
     float scale_h4, scale_w4;  // quarter-res -> full-res
 };
 
-hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, int B,
+// avg = (bilinear x2 of hm_q + hm_h) / 2; coarse (optional) = the maximum of every 4x4 block of avg, [B,K,ceil(hh/4),ceil(wh/4)]
+hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, float *coarse, int B,
                                 int K, int hq, int wq, hipStream_t s);
 // per (b,k,tile): top-M candidates of the NMS'ed map as sortable keys + exact values
 // skip_thr: tiles whose values cannot exceed it emit no candidates (-INFINITY: every tile is processed, the exact top-k)
+// coarse (optional, mode 0): the 4x4-block maxima launch_stage_average left -- inactive tiles are recognised from those alone
 hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, unsigned long long *cand_key, float *cand_val, float *cellmax,
-                                float skip_thr, hipStream_t s);
+                                float skip_thr, const float *coarse, hipStream_t s);
 // images flagged HH_DECODE_FALLBACK: joints[b, 0, k] = the top-1 candidate of joint k recomputed from the map
 hipError_t launch_fallback_top1(const DecodeSrc &src, int M, const int32_t *flags, float *joints, hipStream_t s);
 // per (b,k): merge the tiles' candidates -> scores_k, coords_k (x,y), tags_k
 hipError_t launch_topk_merge(const DecodeSrc &src, int M, int ntiles, unsigned long long *cand_key, const float *cand_val,
                              float *tags_k, int32_t *coords_k, float *scores_k, hipStream_t s);
-// per image: match_by_tag (+ the "no group" fallback); joints [B,M,K,3+E], num_people [B]
+// per image: match_by_tag (+ the "no group" fallback); joints [B,M,K,3+E], num_people [B].  bounds_src != nullptr (mode 0, refine):
+// extra workgroups of the launch also write the tag bounds of the refine scans into tagb and clear the 8 queue counters of ws_jobs
 hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const float *scores_k, int B, int K, int M, int E,
                         double det_thr, double tag_thr, float *joints, int32_t *num_people, float *ws_tags, int32_t *flags,
-                        hipStream_t s);
+                        const DecodeSrc *bounds_src, float *tagb, int32_t *ws_jobs, hipStream_t s);
 // per image: quarter-pixel adjust (optional) and person scores
 // adjust + person scores + (refine != 0) the mean tag of every person and the lists of its missing joints
 hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, int refine, float *joints, const int32_t *num_people, float *scores,
                                 float *ws_prev, int32_t *ws_jobs, hipStream_t s);
-// refine: tag bounds + cleared work lists (in front of launch_adjust_scores), then the full-map argmax for every missing joint
-hipError_t launch_refine_prepare(const DecodeSrc &src, int M, unsigned long long *ws_best, int32_t *ws_jobs, float *tagb, hipStream_t s);
-hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev,
-                         unsigned long long *ws_best, int32_t *ws_jobs, const float *cellmax, float *tagb, hipStream_t s);
+// refine: the full-map argmax for every missing joint (work lists from launch_adjust_scores, tag bounds from launch_match), applied
+// to `joints` by the scanning workgroup
+hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const float *ws_prev, const int32_t *ws_jobs, const float *cellmax,
+                         const float *tagb, hipStream_t s);
 // dst (+)= weight * bilinear(src -> HxW), torch CPU arithmetic, any ratio (multi-scale heatmap aggregation)
 hipError_t launch_resize_accumulate(const float *src, int64_t src_bs, int B, int K, int h, int w, float *dst, int64_t dst_bs, int H,
                                     int W, float weight, int init, hipStream_t s);

@@ -48,28 +48,52 @@ __device__ __forceinline__ float tag_at(const DecodeSrc &s, int b, int k, int y,
 
 // ------------------------------------------------------------------ stage average
 // results.py:225-226: match_heatmaps_size (1/4 -> 1/2) then torch.stack(...).mean(dim=0)
+// Round 3: the pass also leaves the maximum of every 4x4 block of the average it writes (`coarse`, [B,K,ceil(hh/4),ceil(wh/4)]):
+// the NMS pass decides from ~100 of those whether a tile can hold anything above det_thr, instead of reading the tile's 34x34
+// half-res values to find out (three tiles in four cannot).  A workgroup therefore walks GROUPS of 4 consecutive rows (group g =
+// band, band + nband, ...: the eight workgroups of a plane still stream one contiguous 32-row piece of it at a time), a thread
+// keeps the maximum of its column over the group and 4 neighbouring lanes combine theirs.  fmaxf drops NaNs, as the NMS pass's own
+// tile maximum does.
 __global__ __launch_bounds__(256) void stage_average_kernel(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs,
-                                                            float *avg, int K, int hq, int wq, float sy, float sx)
+                                                            float *avg, float *__restrict__ coarse, int K, int hq, int wq, float sy, float sx)
 {
     const int hh = 2 * hq, wh = 2 * wq;
     const int k = blockIdx.x, b = blockIdx.y, band = blockIdx.z, nband = gridDim.z;
     const float *q = hm_q + (size_t)b * hm_q_bs + (size_t)k * hq * wq;
     const float *hsrc = hm_h + (size_t)b * hm_h_bs + (size_t)k * hh * wh;
     float *dst = avg + ((size_t)b * K + k) * hh * wh;
-    for (int x = threadIdx.x; x < wh; x += 256) {
-        const Lin lx = src_index(wq, sx, x);
-        for (int y = band; y < hh; y += nband) {
-            const float up = bilerp(q, wq, src_index(hq, sy, y), lx);
-            dst[(size_t)y * wh + x] = (up + hsrc[(size_t)y * wh + x]) / 2.0f;
+    const int ch = (hh + 3) >> 2, cw = (wh + 3) >> 2;
+    float *cdst = coarse ? coarse + ((size_t)b * K + k) * ch * cw : nullptr;
+    for (int x0 = 0; x0 < wh; x0 += 256) {  // (every lane stays in the loop: the lanes of a 4-column block exchange their maxima)
+        const int x = x0 + threadIdx.x;
+        const bool xin = x < wh;
+        const Lin lx = src_index(wq, sx, xin ? x : wh - 1);
+        for (int g = band; g < ch; g += nband) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = 4 * g + r;
+                if (xin && y < hh) {
+                    const float up = bilerp(q, wq, src_index(hq, sy, y), lx);
+                    const float v = (up + hsrc[(size_t)y * wh + x]) / 2.0f;
+                    dst[(size_t)y * wh + x] = v;
+                    m = fmaxf(m, v);
+                }
+            }
+            if (cdst) {
+                m = fmaxf(m, __shfl_xor(m, 1));
+                m = fmaxf(m, __shfl_xor(m, 2));
+                if (xin && (threadIdx.x & 3) == 0) cdst[(size_t)g * cw + (x >> 2)] = m;
+            }
         }
     }
 }
 
-hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, int B,
+hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, float *coarse, int B,
                                 int K, int hq, int wq, hipStream_t s)
 {
     const float sy = (float)hq / (float)(2 * hq), sx = (float)wq / (float)(2 * wq);
-    hipLaunchKernelGGL(stage_average_kernel, dim3(K, B, 8), dim3(256), 0, s, hm_q, hm_q_bs, hm_h, hm_h_bs, avg, K, hq, wq, sy, sx);
+    hipLaunchKernelGGL(stage_average_kernel, dim3(K, B, 8), dim3(256), 0, s, hm_q, hm_q_bs, hm_h, hm_h_bs, avg, coarse, K, hq, wq, sy, sx);
     return hipGetLastError();
 }
 
@@ -127,7 +151,8 @@ __device__ long long g_nms_dbg[4096 * 8];
 #endif
 
 __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src, int M, int tiles_x, int ntile, u64 *__restrict__ cand_key,
-                                                            float *__restrict__ cand_val, float *__restrict__ cellmax, float skip_thr)
+                                                            float *__restrict__ cand_val, float *__restrict__ cellmax, float skip_thr,
+                                                            const float *__restrict__ coarse)
 {
     // Geometry: a 60x60 tile has a 64x64 halo'ed neighbourhood, so in every pass a wave's 64 lanes are 64 columns (or 64
     // rows x 4 strips are the 256 threads) with nobody idle.
@@ -169,6 +194,34 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
         const bool xb = X <= 0, xodd = X & 1;
         const int ca = min(xodd ? max(g, 0) : (xb ? max(g, 0) : g - 1), wh - 1), cb = min(ca + 1, wh - 1);
         const float wxa = xodd ? 0.75f : (xb ? 1.f : 0.25f), wxb = xodd ? 0.25f : (xb ? 0.f : 0.75f);
+        // the skip path of an inactive tile: no candidates, one upper bound for all its 4x4 cells
+        auto skip_tile = [&](float bound) {
+            if (tid < M) cand_key[((((size_t)b * src.K + k) * ntile) + tile) * M + tid] = 0ull;
+            if (tid < (TS / 4) * (TS / 4)) {
+                const int cy = tid / (TS / 4), cx = tid % (TS / 4);
+                const int Yc = y0 + 4 * cy, Xc = x0 + 4 * cx;
+                if (Yc < src.H && Xc < src.W)
+                    reinterpret_cast<unsigned short *>(cellmax)[(((size_t)b * src.K + k) * (src.H >> 2) + (Yc >> 2)) * (src.W >> 2) + (Xc >> 2)] =
+                        bf16_ceil(bound);
+            }
+        };
+        if (coarse) {
+            // Round 3: the maxima of the 4x4 blocks of the average (stage_average_kernel) that cover every half-res value this tile
+            // and its halo interpolate -- rows py0 .. py0 + PR - 1, columns (x0 - 2) / 2 - 1 .. (x0 + 61) / 2 + 1, clamped --, at most
+            // 10 x 10 of them.  Every wave reduces the same values (no barrier); below the threshold the tile leaves here, after
+            // two loads per lane instead of eighteen and a barrier.  Above it, the exact test further down still runs.
+            const int ch = (hh + 3) >> 2, cw = (wh + 3) >> 2;
+            const int gy0 = py0 >> 2, gy1 = min(py0 + PR - 1, hh - 1) >> 2;
+            const int gx0 = max(((x0 - 2) >> 1) - 1, 0) >> 2, gx1 = min(((x0 + TS + 1) >> 1) + 1, wh - 1) >> 2;
+            const int nx = gx1 - gx0 + 1, n = nx * (gy1 - gy0 + 1);
+            const float *cm = coarse + ((size_t)b * src.K + k) * ch * cw;
+            float m = -INFINITY;
+            for (int i = lane; i < n; i += 64) m = fmaxf(m, cm[(size_t)(gy0 + i / nx) * cw + gx0 + i % nx]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            const float bound = m + 4e-7f * fabsf(m);
+            if (bound <= skip_thr) { skip_tile(bound); return; }
+        }
         constexpr int NR = (PR + 3) / 4;  // rows per wave; every load is issued before the first use (one round trip, not NR)
         float ga[NR], gb[NR];
 #pragma unroll
@@ -192,14 +245,7 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             // refine kernel gets ONE upper bound for all its 4x4 cells, the tile's: such a cell is only ever looked at by a scan
             // whose best value so far is below det_thr, and this path -- two loads per row, a maximum, 225 stores -- is what most
             // workgroups of the launch run (per-cell bounds from the interpolated rows cost it a third more).
-            if (tid < M) cand_key[((((size_t)b * src.K + k) * ntile) + tile) * M + tid] = 0ull;
-            if (tid < (TS / 4) * (TS / 4)) {
-                const int cy = tid / (TS / 4), cx = tid % (TS / 4);
-                const int Y = y0 + 4 * cy, X = x0 + 4 * cx;
-                if (Y < src.H && X < src.W)
-                    reinterpret_cast<unsigned short *>(cellmax)[(((size_t)b * src.K + k) * (src.H >> 2) + (Y >> 2)) * (src.W >> 2) + (X >> 2)] =
-                        bf16_ceil(tmax + 4e-7f * fabsf(tmax));
-            }
+            skip_tile(tmax + 4e-7f * fabsf(tmax));
             return;
         }
 #pragma unroll
@@ -429,11 +475,12 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     }
 }
 
-hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, u64 *cand_key, float *cand_val, float *cellmax, float skip_thr, hipStream_t s)
+hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, u64 *cand_key, float *cand_val, float *cellmax, float skip_thr,
+                                const float *coarse, hipStream_t s)
 {
     const int tiles_x = (src.W + HH_NMS_TILE - 1) / HH_NMS_TILE, tiles_y = (src.H + HH_NMS_TILE - 1) / HH_NMS_TILE;
     hipLaunchKernelGGL(nms_tile_topk_kernel, dim3(tiles_x * tiles_y * src.K * src.B), dim3(256), 0, s, src, M, tiles_x,
-                       tiles_x * tiles_y, cand_key, cand_val, cellmax, skip_thr);
+                       tiles_x * tiles_y, cand_key, cand_val, cellmax, skip_thr, coarse);
     return hipGetLastError();
 }
 
@@ -648,6 +695,50 @@ __device__ __forceinline__ float np_mean18(const float *rows, int n)
     return __fdiv_rn(res, (float)n);
 }
 
+// ------------------------------------------------------------------ refine, step (1b): tag bounds
+// per (b,k) quarter-res cell: [lo, hi] of the 3x3 tag taps (slack included) -- shared by every person whose missing joint k is
+// searched on that map (refine_argmax_kernel).  It needs the input maps only, and the matching kernel below keeps ONE wave per
+// image busy for 120-760 us while the rest of the chip idles: since round 3 the bounds are computed by extra 64-thread workgroups
+// of the matching launch (virtual block vb of the bounds = blockIdx.x - B), one launch and ~25 us of the decode's critical path
+// less.  Virtual block 0 also clears the 8 queue counters of the arg-max pass (filled by adjust_scores_kernel, behind this launch).
+// thread = one quarter-res column x TBR consecutive rows: the 3-wide row minima / maxima are made once per source row and
+// slide down the column (3.75 loads per cell instead of 9; clamped border rows / columns repeat a tap, which min / max ignore)
+constexpr int TBR = 8;
+__device__ __forceinline__ void tag_bounds_part(const DecodeSrc &src, float *__restrict__ tagb, int32_t *__restrict__ ws_jobs, int vb, int lane)
+{
+    if (vb == 0 && lane < 8) ws_jobs[lane] = 0;
+    const int hq = src.H >> 2, wq = src.W >> 2, E = src.E;
+    const int nrb = (hq + TBR - 1) / TBR, per_map = nrb * wq;
+    const long long L = (long long)vb * 64 + lane;
+    if (L >= (long long)src.B * src.K * per_map) return;
+    const int map = (int)(L / per_map), it = (int)(L % per_map);
+    const int k = map % src.K, b = map / src.K;
+    {
+        const int qx = it % wq, qy0 = (it / wq) * TBR;
+        const int xa = max(qx - 1, 0), xb = min(qx + 1, wq - 1);
+        for (int e = 0; e < E; ++e) {
+            const float *tq = src.tags_q[e] + (size_t)b * src.tags_bs[e] + (size_t)k * hq * wq;
+            float rlo[TBR + 2], rhi[TBR + 2];
+#pragma unroll
+            for (int r = 0; r < TBR + 2; ++r) {
+                const float *row = tq + (size_t)min(max(qy0 - 1 + r, 0), hq - 1) * wq;
+                const float t0 = row[xa], t1 = row[qx], t2 = row[xb];
+                rlo[r] = fminf(fminf(t0, t1), t2); rhi[r] = fmaxf(fmaxf(t0, t1), t2);
+            }
+#pragma unroll
+            for (int r = 0; r < TBR; ++r) {
+                if (qy0 + r >= hq) break;
+                const float lo = fminf(fminf(rlo[r], rlo[r + 1]), rlo[r + 2]), hi = fmaxf(fmaxf(rhi[r], rhi[r + 1]), rhi[r + 2]);
+                const float slack = 1e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-30f;  // >> 3 roundings of a convex combination
+                // stored as a bf16 pair in one dword (lo rounded DOWN, hi rounded UP: the bound only gets looser), which
+                // halves what the arg-max scans have to read per cell
+                reinterpret_cast<unsigned *>(tagb)[(((size_t)b * src.K + k) * hq * wq + (size_t)(qy0 + r) * wq + qx) * E + e] =
+                    (unsigned)bf16_floor(lo - slack) | ((unsigned)bf16_ceil(hi + slack) << 16);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ match_by_tag
 // grouping.py:85-145 with munkres 1.1.4 (munkres.py:114-340) restated wave-parallel: one wave per image.  The cost matrix
 // (float64) is built in LDS, then column j lives in the registers of lane j; the zero pattern of row i is a 64-bit mask on
@@ -807,10 +898,15 @@ __constant__ int c_joints_order[17] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 7, 8, 9, 10,
 __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const int32_t *coords_k, const float *scores_k, int K, int M, int E,
                                                    double det_thr,
                                                    double tag_thr, float *__restrict__ joints, int32_t *__restrict__ num_people,
-                                                   float *__restrict__ ws_tags, int32_t *__restrict__ flags, int stage)
+                                                   float *__restrict__ ws_tags, int32_t *__restrict__ flags, int stage, int nimg,
+                                                   const DecodeSrc src, float *__restrict__ tagb, int32_t *__restrict__ ws_jobs)
 {
     __shared__ MatchShared S;
     extern __shared__ float staged[];  // the image's candidates and group tag lists, when they fit (stage != 0)
+    if ((int)blockIdx.x >= nimg) {  // the workgroups behind the images': tag bounds for the refine scans (tag_bounds_part)
+        tag_bounds_part(src, tagb, ws_jobs, (int)blockIdx.x - nimg, (int)threadIdx.x);
+        return;
+    }
     const int b = blockIdx.x, lane = threadIdx.x, D = 3 + E;
     float *J = joints + (size_t)b * M * K * D;
     float *GT = ws_tags + (size_t)b * M * (K + 1) * E;  // per group: list of member tags
@@ -980,12 +1076,19 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
 
 hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const float *scores_k, int B, int K, int M, int E,
                         double det_thr, double tag_thr, float *joints, int32_t *num_people, float *ws_tags, int32_t *flags,
-                        hipStream_t s)
+                        const DecodeSrc *bounds_src, float *tagb, int32_t *ws_jobs, hipStream_t s)
 {
     const size_t bytes = ((size_t)K * M * (E + 3) + (size_t)M * (K + 1) * E) * 4;  // candidates + group tag lists
     const int stage = bytes <= 40 * 1024;
-    hipLaunchKernelGGL(match_kernel, dim3(B), dim3(64), stage ? bytes : 0, s, tags_k, coords_k, scores_k, K, M, E, det_thr, tag_thr,
-                       joints, num_people, ws_tags, flags, stage);
+    int extra = 0;
+    DecodeSrc src{};
+    if (bounds_src) {  // + the tag bounds of the refine scans (and the cleared queue counters) in the same launch
+        src = *bounds_src;
+        const long long units = (long long)src.B * src.K * (((src.H >> 2) + TBR - 1) / TBR) * (src.W >> 2);
+        extra = (int)((units + 63) / 64);
+    }
+    hipLaunchKernelGGL(match_kernel, dim3(B + extra), dim3(64), stage ? bytes : 0, s, tags_k, coords_k, scores_k, K, M, E, det_thr, tag_thr,
+                       joints, num_people, ws_tags, flags, stage, B, src, tagb, ws_jobs);
     return hipGetLastError();
 }
 
@@ -1059,49 +1162,7 @@ hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, int ref
 
 // ------------------------------------------------------------------ refine
 // grouping.py:193-250.  (1) per person: the mean tag of its detected joints and the lists of its missing joints: adjust_scores_kernel.
-// (1b) per (b,k) quarter-res cell: [lo, hi] of the 3x3 tag taps (slack included) -- shared by every person
-// The launch also clears the work lists of the arg-max pass (ws_best: n_best entries, ws_jobs: the 8 queue counters), one entry
-// per thread of the grid: two fill launches less in front of refine_mean_kernel.
-__global__ __launch_bounds__(256) void tag_bounds_kernel(const DecodeSrc src, float *__restrict__ tagb, u64 *__restrict__ ws_best,
-                                                         int n_best, int32_t *__restrict__ ws_jobs)
-{
-    {
-        const size_t id = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-        if (id < (size_t)n_best) ws_best[id] = 0ull;
-        if (id < 8) ws_jobs[id] = 0;
-    }
-    // thread = one quarter-res column x TBR consecutive rows: the 3-wide row minima / maxima are made once per source row and
-    // slide down the column (3.75 loads per cell instead of 9; clamped border rows / columns repeat a tap, which min / max ignore)
-    constexpr int TBR = 8;
-    const int hq = src.H >> 2, wq = src.W >> 2, E = src.E;
-    const int k = blockIdx.y, b = blockIdx.z;
-    const int nrb = (hq + TBR - 1) / TBR;
-    for (int it = blockIdx.x * 256 + threadIdx.x; it < nrb * wq; it += gridDim.x * 256) {
-        const int qx = it % wq, qy0 = (it / wq) * TBR;
-        const int xa = max(qx - 1, 0), xb = min(qx + 1, wq - 1);
-        for (int e = 0; e < E; ++e) {
-            const float *tq = src.tags_q[e] + (size_t)b * src.tags_bs[e] + (size_t)k * hq * wq;
-            float rlo[TBR + 2], rhi[TBR + 2];
-#pragma unroll
-            for (int r = 0; r < TBR + 2; ++r) {
-                const float *row = tq + (size_t)min(max(qy0 - 1 + r, 0), hq - 1) * wq;
-                const float t0 = row[xa], t1 = row[qx], t2 = row[xb];
-                rlo[r] = fminf(fminf(t0, t1), t2); rhi[r] = fmaxf(fmaxf(t0, t1), t2);
-            }
-#pragma unroll
-            for (int r = 0; r < TBR; ++r) {
-                if (qy0 + r >= hq) break;
-                const float lo = fminf(fminf(rlo[r], rlo[r + 1]), rlo[r + 2]), hi = fmaxf(fmaxf(rhi[r], rhi[r + 1]), rhi[r + 2]);
-                const float slack = 1e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-30f;  // >> 3 roundings of a convex combination
-                // stored as a bf16 pair in one dword (lo rounded DOWN, hi rounded UP: the bound only gets looser), which
-                // halves what the arg-max scans have to read per cell
-                reinterpret_cast<unsigned *>(tagb)[(((size_t)b * src.K + k) * hq * wq + (size_t)(qy0 + r) * wq + qx) * E + e] =
-                    (unsigned)bf16_floor(lo - slack) | ((unsigned)bf16_ceil(hi + slack) << 16);
-            }
-        }
-    }
-}
-
+// (1b) per (b,k) quarter-res cell: [lo, hi] of the 3x3 tag taps: tag_bounds_part(), in front of match_kernel (it rides in that launch).
 // (2) per (person, joint) with score == 0: argmax over the full map of hm - round(||tag - mean||)
 // (first index among equal values, as np.argmax).  Exact branch-and-bound over 4x4-pixel cells:
 //   ub(cell) = max_hm(cell) - rint(lower bound of the tag distance over the cell) >= every value in the cell,
@@ -1111,7 +1172,7 @@ __global__ __launch_bounds__(256) void tag_bounds_kernel(const DecodeSrc src, fl
 // bound, and only cells with ub >= that bound are evaluated (typically a handful out of H*W/16).
 __global__ __launch_bounds__(256, 4) void refine_argmax_kernel(const DecodeSrc src, int M, const int32_t *__restrict__ ws_jobs,
                                                             const float *__restrict__ ws_prev, const float *__restrict__ cellmax,
-                                                            const float *__restrict__ tagb, u64 *__restrict__ ws_best)
+                                                            const float *__restrict__ tagb, float *__restrict__ joints)
 {
     __shared__ u64 wbest[4];
     const int tid = threadIdx.x, E = src.E;
@@ -1279,53 +1340,33 @@ __global__ __launch_bounds__(256, 4) void refine_argmax_kernel(const DecodeSrc s
         if (tid == 0) {
             u64 g = wbest[0];
             for (int w = 1; w < 4; ++w) g = wbest[w] > g ? wbest[w] : g;
-            ws_best[((size_t)b * M + p) * src.K + k] = g;
+            // (3) grouping.py:238-249: the joint is filled in if the value at the arg-max is positive (it had score 0: only such
+            // joints are queued), with the quarter-pixel shift of `adjust` in float64 as numpy computes it.  Nothing else reads or
+            // writes this joint's slot, so the job's own workgroup applies it (round 2: a launch of its own over a result table).
+            if (g != 0ull) {  // (every scan evaluates at least one pixel, and no key is 0)
+                float *j = joints + (((size_t)b * M + p) * src.K + k) * (3 + E);
+                const unsigned idx = 0xffffffffu - (unsigned)(g & 0xffffffffull);
+                const int y = (int)(idx / (unsigned)src.W), x = (int)(idx % (unsigned)src.W);
+                const int xr = min(x + 1, src.W - 1), xl = max(x - 1, 0), yd = min(y + 1, src.H - 1), yu = max(y - 1, 0);
+                // (all five samples are fetched before the first is looked at: one round trip, not three)
+                const float val = heat_at(src, b, k, y, x);
+                const float hr = heat_at(src, b, k, y, xr), hl = heat_at(src, b, k, y, xl), hd = heat_at(src, b, k, yd, x), hu = heat_at(src, b, k, yu, x);
+                if (val > 0.f) {
+                    double fx = (double)x + 0.5, fy = (double)y + 0.5;
+                    if (hr > hl) fx += 0.25; else fx -= 0.25;
+                    if (hd > hu) fy += 0.25; else fy -= 0.25;
+                    j[0] = (float)fx; j[1] = (float)fy; j[2] = val;
+                }
+            }
         }
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(64) void refine_apply_kernel(const DecodeSrc src, int M, float *__restrict__ joints,
-                                                          const int32_t *__restrict__ num_people, const u64 *__restrict__ ws_best)
+hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const float *ws_prev, const int32_t *ws_jobs, const float *cellmax,
+                         const float *tagb, hipStream_t s)
 {
-    const int p = blockIdx.x, b = blockIdx.y, k = threadIdx.x, D = 3 + src.E;
-    if (p >= num_people[b] || k >= src.K) return;
-    const u64 g = ws_best[((size_t)b * M + p) * src.K + k];
-    if (g == 0ull) return;  // joint was present (or the person has no tag): nothing scanned
-    float *j = joints + (((size_t)b * M + p) * src.K + k) * D;
-    const unsigned idx = 0xffffffffu - (unsigned)(g & 0xffffffffull);
-    const int y = (int)(idx / (unsigned)src.W), x = (int)(idx % (unsigned)src.W);
-    const float val = heat_at(src, b, k, y, x);
-    if (val > 0.f) {
-        double fx = (double)x + 0.5, fy = (double)y + 0.5;
-        const int xr = min(x + 1, src.W - 1), xl = max(x - 1, 0), yd = min(y + 1, src.H - 1), yu = max(y - 1, 0);
-        if (heat_at(src, b, k, y, xr) > heat_at(src, b, k, y, xl)) fx += 0.25; else fx -= 0.25;
-        if (heat_at(src, b, k, yd, x) > heat_at(src, b, k, yu, x)) fy += 0.25; else fy -= 0.25;
-        j[0] = (float)fx; j[1] = (float)fy; j[2] = val;
-    }
-}
-
-// what the refine passes need from the input maps alone (tag bounds) + cleared work lists: in front of adjust_scores_kernel, which
-// fills the lists
-hipError_t launch_refine_prepare(const DecodeSrc &src, int M, unsigned long long *ws_best, int32_t *ws_jobs, float *tagb, hipStream_t s)
-{
-    const int nx = ((((src.H >> 2) + 7) / 8) * (src.W >> 2) + 255) / 256;  // 8 = TBR
-    if (src.mode == 0 && (size_t)nx * 256 >= (size_t)M) {  // (grid threads >= B * M * K entries)
-        hipLaunchKernelGGL(tag_bounds_kernel, dim3(nx, src.K, src.B), dim3(256), 0, s, src, tagb, ws_best, src.B * M * src.K, ws_jobs);
-    } else {
-        if (src.mode == 0) hipLaunchKernelGGL(tag_bounds_kernel, dim3(nx, src.K, src.B), dim3(256), 0, s, src, tagb, ws_best, 0, ws_jobs);
-        hipError_t e = hipMemsetAsync(ws_best, 0, (size_t)src.B * M * src.K * sizeof(u64), s);
-        if (e != hipSuccess) return e;
-        e = hipMemsetAsync(ws_jobs, 0, 32, s);  // the 8 queue counters
-        if (e != hipSuccess) return e;
-    }
-    return hipGetLastError();
-}
-hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const int32_t *num_people, float *ws_prev,
-                         unsigned long long *ws_best, int32_t *ws_jobs, const float *cellmax, float *tagb, hipStream_t s)
-{
-    hipLaunchKernelGGL(refine_argmax_kernel, dim3(2048), dim3(256), 0, s, src, M, ws_jobs, ws_prev, cellmax, tagb, ws_best);
-    hipLaunchKernelGGL(refine_apply_kernel, dim3(M, src.B), dim3(64), 0, s, src, M, joints, num_people, ws_best);
+    hipLaunchKernelGGL(refine_argmax_kernel, dim3(2048), dim3(256), 0, s, src, M, ws_jobs, ws_prev, cellmax, tagb, joints);
     return hipGetLastError();
 }
 

@@ -31,6 +31,7 @@ PlanSwitches PlanSwitches::from_env()
     s.poison_ws = on("HH_POISON_WS");
     s.poison_lds = on("HH_POISON_LDS");
     s.no_head_fold = on("HH_NO_HEAD_FOLD");
+    s.no_conv_db = on("HH_NO_CONV_DB");
     if (const char *fc = getenv("HH_FAT_CUS")) { s.fat_cus = s.fat_cus64 = atoi(fc); if (const char *c2 = strchr(fc, ',')) s.fat_cus64 = atoi(c2 + 1); }
     if (const char *sk = getenv("HH_DEBUG_SKIP")) {
         static const struct { const char *name; unsigned bit; } cats[] = {{"s2big", SK_S2BIG}, {"s2", SK_S2}, {"upadd", SK_UPADD}, {"c1x1", SK_C1X1},
@@ -628,7 +629,7 @@ int hh_family_pick(int ks, int stride, int cin_pad, int coutp, int *KC, int *NT)
     *NT = (coutp % 64 == 0) ? 2 : 1;
     for (int i = 0; i < conv_num_configs(); ++i) {
         const ConvConfig &c = conv_config(i);
-        if (c.KS == ks && c.S == stride && c.KC == *KC && c.NT == *NT) return 0;
+        if (c.KS == ks && c.S == stride && c.KC == *KC && c.NT == *NT && !c.DB) return 0;
     }
     return 1;
 }
@@ -682,6 +683,10 @@ int hh_net::finalize()
             hh_set_error("no kernel family for conv " + l.conv);
             return 1;
         }
+        // the wide 3x3 layers (one wave per SIMD, 8+ chunks): 16-channel chunks on two LDS buffers (conv_mfma.hip, DB)
+        l.db = !sw.no_conv_db && !l.stem2 && l.ks == 3 && l.stride == 1 && !l.transposed && l.mconv.empty() && l.cin >= 128 &&
+               l.cin % 16 == 0 && coutp % 64 == 0;
+        if (l.db) { l.KC = 16; l.NT = 2; }
         l.cin_pad = round_up(l.cin, l.KC);
         const int COUT_T = 32 * l.NT;
         l.ncg = coutp / COUT_T;
@@ -842,7 +847,7 @@ int hh_pick_config(int ks, int stride, int KC, int NT, int Wo)
     int best = -1;
     for (int i = 0; i < conv_num_configs(); ++i) {
         const ConvConfig &c = conv_config(i);
-        if (c.KS != ks || c.S != stride || c.KC != KC || c.NT != NT) continue;
+        if (c.KS != ks || c.S != stride || c.KC != KC || c.NT != NT || c.DB) continue;
         if (best < 0) best = i;
         const bool want16 = Wo <= 16;
         if ((c.TW == 16) == want16) return i;
@@ -854,7 +859,7 @@ static int pick_config(const ConvLayer &l, int Wo)
     int best = -1;
     for (int i = 0; i < conv_num_configs(); ++i) {
         const ConvConfig &c = conv_config(i);
-        if (c.KS != l.ks || c.S != l.stride || c.KC != l.KC || c.NT != l.NT) continue;
+        if (c.KS != l.ks || c.S != l.stride || c.KC != l.KC || c.NT != l.NT || c.DB != l.db) continue;
         if (best < 0) best = i;
         const bool want16 = Wo <= 16;
         if ((c.TW == 16) == want16) return i;

@@ -49,6 +49,7 @@ struct ConvLayer {
     size_t phase_stride = 0;
     // chosen at finalize
     int KC = 0, NT = 0, cin_pad = 0, ncg = 0;
+    int db = 0;  // 1: the double-buffered instantiation (3x3 stride 1, >= 128 input channels; PlanSwitches::no_conv_db)
     bf16_raw *d_w = nullptr;
     float *d_bias = nullptr;
     // fp8 path: e4m3 weights with one scale per output channel; d_mult[co] = s_in * w_scale[co] is rewritten whenever the
@@ -143,6 +144,7 @@ struct PlanSwitches {
     // lanes find free CUs while either runs: forward 4.48 -> 4.39 ms, +1.5-2 % img/s (three alternations, profiles/r03_ab.md).
     // HH_FAT_CUS=n[,m] sets them (256 = one per CU, the round-2 plan); a quarter of the chip for the 64-channel block loses 6 %.
     int fat_cus = 0, fat_cus64 = 0;
+    bool no_conv_db = false;       // HH_NO_CONV_DB=1: the 128- / 256-channel 3x3 convs on the single-buffer KC = 32 instantiations (round 2)
     bool no_head_fold = false;     // HH_NO_HEAD_FOLD=1: init_heatmaps_head writes its output into the concat buffer, the transposed conv reads it
     bool poison_lds = false;       // HH_POISON_LDS=1 (tests): every CU's LDS filled with NaN patterns in front of every launch
     unsigned debug_skip = 0;       // HH_DEBUG_SKIP=cat[,cat..] (measurement only, results are WRONG): launches of these categories are not

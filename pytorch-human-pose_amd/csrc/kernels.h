@@ -58,12 +58,14 @@ struct ConvParams {
 // Tile configuration of one kernel instantiation.
 struct ConvConfig {
     int KS, S, KC, NT, WC, PT, TW;
+    int DB;  // 1: the K loop runs on two LDS buffers (conv_mfma.hip), each followed by 16 bytes per thread for staging units without a destination
     int cout_t() const { return 32 * NT * WC; }
     int th() const { return (4 / WC) * PT * (32 / TW); }
     size_t lds_bytes() const {
         int PH = (th() - 1) * S + KS, PW = (TW - 1) * S + KS;
         size_t patch = ((size_t)PH * PW * (KC * 2 + 16) + 15) & ~(size_t)15;
-        return patch + (size_t)KS * KS * KC * cout_t() * 2;
+        const size_t buf = patch + (size_t)KS * KS * KC * cout_t() * 2;
+        return DB ? 2 * (buf + 256 * 16) : buf;
     }
 };
 
