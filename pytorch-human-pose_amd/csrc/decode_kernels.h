@@ -28,14 +28,12 @@ struct DecodeSrc {
     float scale_h4, scale_w4;  // quarter-res -> full-res
 };
 
-// avg = (bilinear x2 of hm_q + hm_h) / 2; coarse (optional) = the maximum of every 4x4 block of avg, [B,K,ceil(hh/4),ceil(wh/4)]
-hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, float *coarse, int B,
+hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, int B,
                                 int K, int hq, int wq, hipStream_t s);
 // per (b,k,tile): top-M candidates of the NMS'ed map as sortable keys + exact values
 // skip_thr: tiles whose values cannot exceed it emit no candidates (-INFINITY: every tile is processed, the exact top-k)
-// coarse (optional, mode 0): the 4x4-block maxima launch_stage_average left -- inactive tiles are recognised from those alone
 hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, unsigned long long *cand_key, float *cand_val, float *cellmax,
-                                float skip_thr, const float *coarse, hipStream_t s);
+                                float skip_thr, hipStream_t s);
 // images flagged HH_DECODE_FALLBACK: joints[b, 0, k] = the top-1 candidate of joint k recomputed from the map
 hipError_t launch_fallback_top1(const DecodeSrc &src, int M, const int32_t *flags, float *joints, hipStream_t s);
 // per (b,k): merge the tiles' candidates -> scores_k, coords_k (x,y), tags_k

@@ -48,52 +48,28 @@ __device__ __forceinline__ float tag_at(const DecodeSrc &s, int b, int k, int y,
 
 // ------------------------------------------------------------------ stage average
 // results.py:225-226: match_heatmaps_size (1/4 -> 1/2) then torch.stack(...).mean(dim=0)
-// Round 3: the pass also leaves the maximum of every 4x4 block of the average it writes (`coarse`, [B,K,ceil(hh/4),ceil(wh/4)]):
-// the NMS pass decides from ~100 of those whether a tile can hold anything above det_thr, instead of reading the tile's 34x34
-// half-res values to find out (three tiles in four cannot).  A workgroup therefore walks GROUPS of 4 consecutive rows (group g =
-// band, band + nband, ...: the eight workgroups of a plane still stream one contiguous 32-row piece of it at a time), a thread
-// keeps the maximum of its column over the group and 4 neighbouring lanes combine theirs.  fmaxf drops NaNs, as the NMS pass's own
-// tile maximum does.
 __global__ __launch_bounds__(256) void stage_average_kernel(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs,
-                                                            float *avg, float *__restrict__ coarse, int K, int hq, int wq, float sy, float sx)
+                                                            float *avg, int K, int hq, int wq, float sy, float sx)
 {
     const int hh = 2 * hq, wh = 2 * wq;
     const int k = blockIdx.x, b = blockIdx.y, band = blockIdx.z, nband = gridDim.z;
     const float *q = hm_q + (size_t)b * hm_q_bs + (size_t)k * hq * wq;
     const float *hsrc = hm_h + (size_t)b * hm_h_bs + (size_t)k * hh * wh;
     float *dst = avg + ((size_t)b * K + k) * hh * wh;
-    const int ch = (hh + 3) >> 2, cw = (wh + 3) >> 2;
-    float *cdst = coarse ? coarse + ((size_t)b * K + k) * ch * cw : nullptr;
-    for (int x0 = 0; x0 < wh; x0 += 256) {  // (every lane stays in the loop: the lanes of a 4-column block exchange their maxima)
-        const int x = x0 + threadIdx.x;
-        const bool xin = x < wh;
-        const Lin lx = src_index(wq, sx, xin ? x : wh - 1);
-        for (int g = band; g < ch; g += nband) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = 4 * g + r;
-                if (xin && y < hh) {
-                    const float up = bilerp(q, wq, src_index(hq, sy, y), lx);
-                    const float v = (up + hsrc[(size_t)y * wh + x]) / 2.0f;
-                    dst[(size_t)y * wh + x] = v;
-                    m = fmaxf(m, v);
-                }
-            }
-            if (cdst) {
-                m = fmaxf(m, __shfl_xor(m, 1));
-                m = fmaxf(m, __shfl_xor(m, 2));
-                if (xin && (threadIdx.x & 3) == 0) cdst[(size_t)g * cw + (x >> 2)] = m;
-            }
+    for (int x = threadIdx.x; x < wh; x += 256) {
+        const Lin lx = src_index(wq, sx, x);
+        for (int y = band; y < hh; y += nband) {
+            const float up = bilerp(q, wq, src_index(hq, sy, y), lx);
+            dst[(size_t)y * wh + x] = (up + hsrc[(size_t)y * wh + x]) / 2.0f;
         }
     }
 }
 
-hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, float *coarse, int B,
+hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float *hm_h, int64_t hm_h_bs, float *avg, int B,
                                 int K, int hq, int wq, hipStream_t s)
 {
     const float sy = (float)hq / (float)(2 * hq), sx = (float)wq / (float)(2 * wq);
-    hipLaunchKernelGGL(stage_average_kernel, dim3(K, B, 8), dim3(256), 0, s, hm_q, hm_q_bs, hm_h, hm_h_bs, avg, coarse, K, hq, wq, sy, sx);
+    hipLaunchKernelGGL(stage_average_kernel, dim3(K, B, 8), dim3(256), 0, s, hm_q, hm_q_bs, hm_h, hm_h_bs, avg, K, hq, wq, sy, sx);
     return hipGetLastError();
 }
 
@@ -151,8 +127,7 @@ __device__ long long g_nms_dbg[4096 * 8];
 #endif
 
 __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src, int M, int tiles_x, int ntile, u64 *__restrict__ cand_key,
-                                                            float *__restrict__ cand_val, float *__restrict__ cellmax, float skip_thr,
-                                                            const float *__restrict__ coarse)
+                                                            float *__restrict__ cand_val, float *__restrict__ cellmax, float skip_thr)
 {
     // Geometry: a 60x60 tile has a 64x64 halo'ed neighbourhood, so in every pass a wave's 64 lanes are 64 columns (or 64
     // rows x 4 strips are the 256 threads) with nobody idle.
@@ -194,34 +169,6 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
         const bool xb = X <= 0, xodd = X & 1;
         const int ca = min(xodd ? max(g, 0) : (xb ? max(g, 0) : g - 1), wh - 1), cb = min(ca + 1, wh - 1);
         const float wxa = xodd ? 0.75f : (xb ? 1.f : 0.25f), wxb = xodd ? 0.25f : (xb ? 0.f : 0.75f);
-        // the skip path of an inactive tile: no candidates, one upper bound for all its 4x4 cells
-        auto skip_tile = [&](float bound) {
-            if (tid < M) cand_key[((((size_t)b * src.K + k) * ntile) + tile) * M + tid] = 0ull;
-            if (tid < (TS / 4) * (TS / 4)) {
-                const int cy = tid / (TS / 4), cx = tid % (TS / 4);
-                const int Yc = y0 + 4 * cy, Xc = x0 + 4 * cx;
-                if (Yc < src.H && Xc < src.W)
-                    reinterpret_cast<unsigned short *>(cellmax)[(((size_t)b * src.K + k) * (src.H >> 2) + (Yc >> 2)) * (src.W >> 2) + (Xc >> 2)] =
-                        bf16_ceil(bound);
-            }
-        };
-        if (coarse) {
-            // Round 3: the maxima of the 4x4 blocks of the average (stage_average_kernel) that cover every half-res value this tile
-            // and its halo interpolate -- rows py0 .. py0 + PR - 1, columns (x0 - 2) / 2 - 1 .. (x0 + 61) / 2 + 1, clamped --, at most
-            // 10 x 10 of them.  Every wave reduces the same values (no barrier); below the threshold the tile leaves here, after
-            // two loads per lane instead of eighteen and a barrier.  Above it, the exact test further down still runs.
-            const int ch = (hh + 3) >> 2, cw = (wh + 3) >> 2;
-            const int gy0 = py0 >> 2, gy1 = min(py0 + PR - 1, hh - 1) >> 2;
-            const int gx0 = max(((x0 - 2) >> 1) - 1, 0) >> 2, gx1 = min(((x0 + TS + 1) >> 1) + 1, wh - 1) >> 2;
-            const int nx = gx1 - gx0 + 1, n = nx * (gy1 - gy0 + 1);
-            const float *cm = coarse + ((size_t)b * src.K + k) * ch * cw;
-            float m = -INFINITY;
-            for (int i = lane; i < n; i += 64) m = fmaxf(m, cm[(size_t)(gy0 + i / nx) * cw + gx0 + i % nx]);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-            const float bound = m + 4e-7f * fabsf(m);
-            if (bound <= skip_thr) { skip_tile(bound); return; }
-        }
         constexpr int NR = (PR + 3) / 4;  // rows per wave; every load is issued before the first use (one round trip, not NR)
         float ga[NR], gb[NR];
 #pragma unroll
@@ -245,7 +192,14 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
             // refine kernel gets ONE upper bound for all its 4x4 cells, the tile's: such a cell is only ever looked at by a scan
             // whose best value so far is below det_thr, and this path -- two loads per row, a maximum, 225 stores -- is what most
             // workgroups of the launch run (per-cell bounds from the interpolated rows cost it a third more).
-            skip_tile(tmax + 4e-7f * fabsf(tmax));
+            if (tid < M) cand_key[((((size_t)b * src.K + k) * ntile) + tile) * M + tid] = 0ull;
+            if (tid < (TS / 4) * (TS / 4)) {
+                const int cy = tid / (TS / 4), cx = tid % (TS / 4);
+                const int Y = y0 + 4 * cy, X = x0 + 4 * cx;
+                if (Y < src.H && X < src.W)
+                    reinterpret_cast<unsigned short *>(cellmax)[(((size_t)b * src.K + k) * (src.H >> 2) + (Y >> 2)) * (src.W >> 2) + (X >> 2)] =
+                        bf16_ceil(tmax + 4e-7f * fabsf(tmax));
+            }
             return;
         }
 #pragma unroll
@@ -475,12 +429,11 @@ __global__ __launch_bounds__(256) void nms_tile_topk_kernel(const DecodeSrc src,
     }
 }
 
-hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, u64 *cand_key, float *cand_val, float *cellmax, float skip_thr,
-                                const float *coarse, hipStream_t s)
+hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, u64 *cand_key, float *cand_val, float *cellmax, float skip_thr, hipStream_t s)
 {
     const int tiles_x = (src.W + HH_NMS_TILE - 1) / HH_NMS_TILE, tiles_y = (src.H + HH_NMS_TILE - 1) / HH_NMS_TILE;
     hipLaunchKernelGGL(nms_tile_topk_kernel, dim3(tiles_x * tiles_y * src.K * src.B), dim3(256), 0, s, src, M, tiles_x,
-                       tiles_x * tiles_y, cand_key, cand_val, cellmax, skip_thr, coarse);
+                       tiles_x * tiles_y, cand_key, cand_val, cellmax, skip_thr);
     return hipGetLastError();
 }
 

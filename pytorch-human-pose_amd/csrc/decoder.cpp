@@ -1,6 +1,5 @@
 // Host side of the decode path: workspace + launch sequence behind hh_decode / hh_parse.
 #include <cmath>
-#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -13,13 +12,11 @@ struct hh_decoder {
     double det_thr, tag_thr;
     // reserved capacity
     int rB = 0, rH = 0, rW = 0, rE = 0;
-    float *avg = nullptr, *coarse = nullptr, *cellmax = nullptr, *tagb = nullptr, *cand_val = nullptr, *tags_k = nullptr, *scores_k = nullptr, *ws_tags = nullptr, *ws_prev = nullptr;
+    float *avg = nullptr, *cellmax = nullptr, *tagb = nullptr, *cand_val = nullptr, *tags_k = nullptr, *scores_k = nullptr, *ws_tags = nullptr, *ws_prev = nullptr;
     unsigned long long *cand_key = nullptr;
     int32_t *coords_k = nullptr, *flags = nullptr, *ws_jobs = nullptr;  // flags [rB]: HH_DECODE_* bits of the last call
     std::vector<void *> allocs;
     int lastB = 0, lastE = 0;
-    bool have_coarse = false;  // this call's stage average left its 4x4-block maxima in `coarse`
-    bool no_coarse = false;    // HH_DECODE_NO_COARSE=1 (A/B): the NMS pass finds its inactive tiles from the tiles' own values (round 2)
     int exact_topk = 0;   // 1: every tile is processed, so hh_decoder_read_topk returns the reference's full top_k
     int last_exact = 0;
     const int32_t *flags_last = nullptr;
@@ -50,7 +47,6 @@ int hh_decoder::reserve(int B, int H, int W, int E)
     };
     const size_t nt = (size_t)ntiles_of(nH, nW);
     if (alloc((size_t)nB * K * (nH / 2) * (nW / 2) * 4, (void **)&avg)) return 1;
-    if (alloc((size_t)nB * K * ((size_t)nH * nW / 16 + 16) * 4, (void **)&coarse)) return 1;  // 4x4-block maxima of avg: ceil(H/8) * ceil(W/8) <= H * W / 16 for H, W >= 4
     if (alloc((size_t)nB * K * (nH / 4 + 1) * (nW / 4 + 1) * 4, (void **)&cellmax)) return 1;
     if (alloc((size_t)nB * K * (nH / 4 + 1) * (nW / 4 + 1) * nE * 2 * 4, (void **)&tagb)) return 1;
     if (alloc((size_t)nB * K * nt * M * 8, (void **)&cand_key)) return 1;
@@ -79,7 +75,7 @@ int hh_decoder::run(DecodeSrc &src, int adjust, int refine, float *joints, float
     // the largest float <= det_thr: `bound <= skip_thr` then implies `(double)score <= det_thr` for every pixel of the tile
     float thr_f = (float)det_thr;
     if ((double)thr_f > det_thr) thr_f = nextafterf(thr_f, -INFINITY);
-    HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, cellmax, skip ? thr_f : -INFINITY, skip && have_coarse ? coarse : nullptr, s));
+    HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, cellmax, skip ? thr_f : -INFINITY, s));
     last_exact = !skip;
     HH_CHECK_HIP(launch_topk_merge(src, M, nt, cand_key, cand_val, tags_k, coords_k, scores_k, s));
     // (mode 0: the tag bounds of the refine scans and the cleared queue counters ride in the matching launch)
@@ -105,7 +101,6 @@ hh_decoder *hh_decoder_create(int num_kpts, int max_people, double det_thr, doub
     }
     hh_decoder *d = new hh_decoder();
     d->K = num_kpts; d->M = max_people; d->det_thr = det_thr; d->tag_thr = tag_thr;
-    { const char *v = getenv("HH_DECODE_NO_COARSE"); d->no_coarse = v && *v && strcmp(v, "0"); }
     return d;
 }
 void hh_decoder_destroy(hh_decoder *dec)
@@ -126,8 +121,7 @@ int hh_decode(hh_decoder *dec, const float *hm_q, int64_t hm_q_bstride, const fl
     const int H = 4 * hq, W = 4 * wq;
     if (dec->reserve(B, H, W, E)) return 1;
     hipStream_t s = (hipStream_t)stream;
-    HH_CHECK_HIP(launch_stage_average(hm_q, hm_q_bstride, hm_h, hm_h_bstride, dec->avg, dec->no_coarse ? nullptr : dec->coarse, B, dec->K, hq, wq, s));
-    dec->have_coarse = !dec->no_coarse;
+    HH_CHECK_HIP(launch_stage_average(hm_q, hm_q_bstride, hm_h, hm_h_bstride, dec->avg, B, dec->K, hq, wq, s));
     DecodeSrc src{};
     src.mode = 0; src.avg = dec->avg; src.B = B; src.H = H; src.W = W; src.E = E;
     for (int e = 0; e < E; ++e) { src.tags_q[e] = tags_q[e]; src.tags_bs[e] = tags_bstride[e]; }
@@ -141,7 +135,6 @@ int hh_parse(hh_decoder *dec, const float *hm_full, const float *tags_full, int 
     if (B <= 0 || H <= 0 || W <= 0 || (size_t)H * W >= (1u << 24)) { hh_set_error("hh_parse: bad shape (need H*W < 2^24)"); return 1; }
     if (dec->reserve(B, H, W, E)) return 1;
     DecodeSrc src{};
-    dec->have_coarse = false;
     src.mode = 1; src.hm_full = hm_full; src.tags_full = tags_full; src.B = B; src.H = H; src.W = W; src.E = E;
     return dec->run(src, adjust, refine, joints, scores, num_people, flags, (hipStream_t)stream);
 }

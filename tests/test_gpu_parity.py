@@ -182,11 +182,13 @@ def test_schedule_and_fusion_switches(pkg, net_golden):
     """The plan variants behind the engine switches: all-to-all joins (HH_FULL_JOIN=1) give the default plan's bits (same kernels,
     other edges), and so do stage-0 junctions that each store their y (HH_NO_JUNC_PAIR=1: the pair mode makes the previous
     unit's y again with the same arithmetic and the same bf16 rounding); one launch per summed stride-2 conv (HH_NO_FUSION_MERGE=1) rounds the partial sums to bf16 between the launches
-    and so differs from the merged conv by bf16 noise only; both meet the golden tolerance."""
+    and so differs from the merged conv by bf16 noise only, and so do the 128- / 256-channel 3x3 convs on the single-buffer 32-channel-chunk
+    instantiations (HH_NO_CONV_DB=1: the double-buffered form walks 16-channel chunks, another order of the fp32 additions); all meet
+    the golden tolerance."""
     x = torch.from_numpy(pkg.synth.synth_images(2, 128, 128, 1)).to(DEV)
     base, _ = _net(pkg, 32, 1)
     ref = [t.clone() for t in base.forward_raw(x)]
-    for env, exact in ((("HH_FULL_JOIN", "1"), True), (("HH_NO_FUSION_MERGE", "1"), False), (("HH_NO_JUNC_PAIR", "1"), True)):
+    for env, exact in ((("HH_FULL_JOIN", "1"), True), (("HH_NO_FUSION_MERGE", "1"), False), (("HH_NO_JUNC_PAIR", "1"), True), (("HH_NO_CONV_DB", "1"), False)):
         os.environ[env[0]] = env[1]
         try:
             net, _ = _net(pkg, 32, 1)
@@ -242,7 +244,7 @@ def test_forward_does_not_depend_on_stale_lds(pkg):
 
 
 def test_many_live_handles_interleaved_forwards_stay_bit_exact(pkg):
-    """Cross-handle state (round 2's open item): 16 handles over the plan switches stay ALIVE in one process, and B = 1 / B = 4
+    """Cross-handle state (round 2's open item): 17 handles over the plan switches stay ALIVE in one process, and B = 1 / B = 4
     forwards at 512x512 are interleaved over all of them for 50 rounds.  Every bit-exact variant must keep returning the bits a
     fresh default handle gave before the others existed; the two variants that round differently (tile-form block, unmerged
     fusion convs) must each keep returning their own first result."""
@@ -257,7 +259,7 @@ def test_many_live_handles_interleaved_forwards_stay_bit_exact(pkg):
     _same_bits(ref4[1][3], ref1[1][0], "fresh handle: deconv_heatmaps slot 3 vs batch of 1")
     exact = [{}, {"HH_FULL_JOIN": "1"}, {"HH_NO_JUNC_PAIR": "1"}, {"HH_FULL_JOIN": "1", "HH_NO_JUNC_PAIR": "1"}, {}, {}]
     own = [{"HH_NO_STEM_FUSED": "1"}, {"HH_NO_STEM_FUSED": "1", "HH_NO_JUNC_PAIR": "1"}, {"HH_BB32": "tile"}, {"HH_NO_FUSION_MERGE": "1"}, {"HH_NO_BB64": "1"}, {"HH_NO_HEAD_FOLD": "1"}, {"HH_NO_HEAD_FOLD": "1", "HH_FULL_JOIN": "1"},
-           {"HH_BB32": "tile", "HH_FULL_JOIN": "1"}, {"HH_NO_BB64": "1", "HH_NO_FUSION_MERGE": "1"}]
+           {"HH_BB32": "tile", "HH_FULL_JOIN": "1"}, {"HH_NO_BB64": "1", "HH_NO_FUSION_MERGE": "1"}, {"HH_NO_CONV_DB": "1"}]
     nets = []
     for env in exact + own:
         with _switch_env(env):
