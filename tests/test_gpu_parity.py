@@ -352,6 +352,37 @@ def test_decode_bit_exact_vs_reference_golden(pkg, synth, decode_golden):
             assert np.array_equal(sk[0][pos], g[tag + "/scores_k"][pos]) and np.array_equal(ck[0][pos], g[tag + "/coords_k"][pos])
 
 
+def test_decode_fuzz_vs_oracle(pkg, synth):
+    """Seeded sweep beside the 14 reference goldens: 48 constructed cases over ragged map sizes, 0..30 people (more candidates
+    than `max_people` included), one and two embedding maps (flip TTA), both threshold pairs the reference uses (inference
+    0.05 / 0.5, validation 0.1 / 1.0), max_people 5 / 20 / 30, noisy and crowded tags, adjust / refine on and off -- every case must
+    equal the C oracle (the restatement the goldens pin) bit for bit, dtype included, in one batched call per shape."""
+    rng = np.random.default_rng(20261005)
+    shapes = [(20, 28), (24, 40), (32, 32), (40, 24), (48, 64), (64, 64)]  # (model inputs >= 80 px: above torch's small-size bilinear path, DESIGN section 2)
+    for si, (hq, wq) in enumerate(shapes):
+        for emb in (1, 2):
+            cases = []
+            for c in range(4):
+                people = int(rng.integers(0, 31)) if c else 0
+                cases.append(dict(people=people, seed=int(rng.integers(1 << 20)), tag_noise=float(rng.choice([0.02, 0.05, 0.2])),
+                                  spacing=float(rng.choice([0.6, 1.0, 1.7])), drop=float(rng.choice([0.0, 0.15, 0.5]))))
+            maps = [synth.synth_decode_maps(17, hq, wq, cs["people"], seed=cs["seed"], emb=emb, tag_noise=cs["tag_noise"],
+                                            tag_spacing=cs["spacing"], drop_prob=cs["drop"]) for cs in cases]
+            hm_q = torch.from_numpy(np.stack([m[0] for m in maps])).to(DEV)
+            hm_h = torch.from_numpy(np.stack([m[1] for m in maps])).to(DEV)
+            tg = [torch.from_numpy(np.stack([m[2][e] for m in maps])).to(DEV) for e in range(emb)]
+            det, tagt = ((0.05, 0.5), (0.1, 1.0))[(si + emb) % 2]
+            mp = (30, 20, 5)[(si + emb) % 3]
+            adj, ref = bool((si + emb) % 4 != 1), bool((si + emb) % 4 != 2)
+            parser = pkg.MPPEHeatmapParser(17, mp, det, tagt)
+            res = parser.to_lists(*parser.decode_batch_device(hm_q, hm_h, tg, adjust=adj, refine=ref))
+            for b, m in enumerate(maps):
+                rj, rs = orc.decode(m[0], m[1], m[2], max_people=mp, det_thr=det, tag_thr=tagt, adjust=int(adj), refine=int(ref))
+                ctx = (hq, wq, emb, cases[b], det, tagt, mp, adj, ref)
+                assert res[b][0].dtype == rj.dtype and res[b][0].shape == rj.shape and np.array_equal(res[b][0], rj), ctx
+                assert res[b][1].dtype == rs.dtype and np.array_equal(res[b][1], rs), ctx
+
+
 def test_parse_fullres_boundary_bit_exact(pkg, synth, decode_golden):
     """MPPEHeatmapParser.parse on explicit full-resolution maps (the reference's parser boundary)."""
     meta, g = decode_golden
