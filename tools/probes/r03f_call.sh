@@ -1,0 +1,13 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+K="decode or parse or end_to_end or chained or validation or infer_images or evaluate or native or full_size"
+timeout -k 10 800 python -m pytest tests -m gpu -x -q -p no:cacheprovider -k "$K" > gpurun_out/f1_test.log 2>&1
+rc=$?; tail -6 gpurun_out/f1_test.log
+[ $rc -ne 0 ] && exit $rc
+for i in 1 2 3; do
+  echo "base lib : $(HH_LIB=$PWD/scratch/libhhrnet_prev.so timeout -k 10 100 python tools/decode_time.py 2>/dev/null | tail -1)   dense $(HH_LIB=$PWD/scratch/libhhrnet_prev.so HH_DECODE_PEOPLE=27 timeout -k 10 100 python tools/decode_time.py 2>/dev/null | tail -1)"
+  echo "this lib : $(timeout -k 10 100 python tools/decode_time.py 2>/dev/null | tail -1)   dense $(HH_DECODE_PEOPLE=27 timeout -k 10 100 python tools/decode_time.py 2>/dev/null | tail -1)"
+done | tee gpurun_out/f1_decode.log
+bash tools/probes/decode_kstats.sh 2>&1 | grep -v amdgpu.ids | tee gpurun_out/f1_kstats.log
