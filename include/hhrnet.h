@@ -290,6 +290,10 @@ int hh_resize_accumulate(const float *src, int64_t src_bstride, int B, int K, in
 /* Candidates of the last hh_decode/hh_parse call (MPPEHeatmapParser.top_k, grouping.py:147-170),
  * copied to host: tags_k [B,K,max_people,E], coords_k [B,K,max_people,2] (x,y), scores_k [B,K,max_people].
  * Synchronous; for parity tests.                                                        */
+/* Test hook: the matcher's assignment solver (munkres 1.1.4's step machine, grouping.py:55-59, as one wavefront) alone on one
+ * square float64 cost matrix in host memory, n <= 32: star[i] = the column assigned to row i.  Pad a rectangular problem with zeros
+ * as munkres.pad_matrix does.  */
+int hh_debug_munkres(const double *cost, int n, int32_t *star);
 int hh_decoder_read_topk(hh_decoder *dec, float *tags_k, int32_t *coords_k, float *scores_k);
 
 /* get_affine_transform(center, scale, rot=0, output_size, inverse) of base/transforms/utils.py:25-57 -> the 2x3 matrix

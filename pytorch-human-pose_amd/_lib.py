@@ -63,6 +63,7 @@ def _sig(lib):
         "hh_profile_clock": (i32, [vp, i32, C.POINTER(C.c_double)]),
         "hh_conv_config": (i32, [i32, C.POINTER(C.c_int)]),
         "hh_conv_config_double_buffered": (i32, [i32]),
+        "hh_debug_munkres": (i32, [C.POINTER(C.c_double), i32, C.POINTER(C.c_int32)]),
         "hh_debug_conv_bench": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp, i32, C.POINTER(C.c_float)]),
         "hh_debug_bb_bench": (i32, [i32, i32, i32, i32, C.POINTER(C.c_float), vp]),
         "hh_debug_bb_compare": (i32, [i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -102,6 +103,8 @@ def _sig(lib):
         "hh_warp_affine_u8": (i32, [vp, i32, i32, C.POINTER(C.c_double), vp, i32, i32, vp]),
     }
     for name, (res, args) in sigs.items():
+        if name.startswith("hh_debug_") and not hasattr(lib, name):
+            continue  # (test / probe hooks only: an older build of the same ABI behind HH_LIB may lack one)
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

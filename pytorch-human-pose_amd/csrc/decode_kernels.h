@@ -44,6 +44,9 @@ hipError_t launch_topk_merge(const DecodeSrc &src, int M, int ntiles, unsigned l
 hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const float *scores_k, int B, int K, int M, int E,
                         double det_thr, double tag_thr, float *joints, int32_t *num_people, float *ws_tags, int32_t *flags,
                         const DecodeSrc *bounds_src, float *tagb, int32_t *ws_jobs, hipStream_t s);
+// debug: the assignment solver alone, one wave on one n x n float64 matrix (n <= HH_MAX_PEOPLE); out[0..n) = starred column of each
+// row, out[n] = 1 if the iteration guard ran out
+hipError_t launch_munkres_debug(const double *cost, int n, int32_t *out, hipStream_t s);
 // per image: quarter-pixel adjust (optional) and person scores
 // adjust + person scores + (refine != 0) the mean tag of every person and the lists of its missing joints
 hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, int refine, float *joints, const int32_t *num_people, float *scores,

@@ -6,6 +6,8 @@
 
 #include <math.h>
 
+#include <utility>
+
 typedef unsigned long long u64;
 
 // ------------------------------------------------------------------ bilinear sampling
@@ -711,15 +713,48 @@ struct MatchShared {
     int G;
 };
 
-__device__ __forceinline__ u64 readlane_u64(u64 v, int l)
+// Row / column sets of the assignment problem are 32-bit masks (n <= HH_MAX_PEOPLE = 32): one SGPR, one v_readlane / v_writelane.
+static_assert(HH_MAX_PEOPLE <= 32, "the matcher's zero / cover masks are 32-bit");
+__device__ __forceinline__ unsigned readlane_u32(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+// `old` with lane L replaced by the (wave-uniform) val.  L a compile-time constant: ONE v_writelane_b32 (inline asm: this compiler has
+// no builtin for it); a run-time lane would need m0 as the lane select (the VOP3 form takes one SGPR), a register the compiler
+// reserves, so those sites keep the compare + select.
+template <int L>
+__device__ __forceinline__ int writelane_const(int val, int old)
 {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
-    return ((u64)hi << 32) | lo;
+    // (s_nop 1: on gfx940+ a VALU that reads an SGPR a VALU has just written -- the ballot -- needs two wait states, and the compiler
+    // does not look into an asm statement to count them: without it the lane got the PREVIOUS ballot now and then)
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(L));
+    return old;
+}
+__device__ __forceinline__ int setlane_i32(int val, int l, int old, int lane) { return lane == l ? val : old; }
+template <typename F, int... I>
+__device__ __forceinline__ void mk_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void mk_for(F &&f) { mk_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// v of the lane ROT places further up its 16-lane row (row_ror): a vector-pipe move -- the xor shuffles they replace went through
+// the LDS crossbar, twice per double
+template <int ROT>
+__device__ __forceinline__ double row_ror_f64(double v)
+{
+    const u64 b = __builtin_bit_cast(u64, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x120 + ROT, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x120 + ROT, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((u64)(unsigned)hi << 32) | (u64)(unsigned)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const u64 b = __builtin_bit_cast(u64, v);
+    const unsigned lo = readlane_u32((unsigned)b, l), hi = readlane_u32((unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((u64)hi << 32) | lo);
 }
 
 // munkres on the n x n matrix in S.Cm.  -> 0 and `star` = the starred column of row `lane` (-1: none), or 1 if the iteration guard
 // ran out.  NMAX >= n: the length of the unrolled loops (row `lane`, then column `lane`, live in NMAX registers).
+// Round 3, second pass over the step machine (same decisions, fewer instructions on its one wave, whose every instruction's latency
+// is exposed): 32-bit masks; a lane's value is set with v_writelane instead of compare + select; step 4 keeps the set of rows
+// that hold an uncovered zero up to date from the per-COLUMN zero masks (`zt`: uncovering column c adds the rows with a zero in
+// it) instead of recomputing it from every row's mask in every iteration; step 6's minimum runs on row rotations (DPP).
 template <int NMAX>
 __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
 {
@@ -737,7 +772,8 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
     }
     __syncthreads();
     double col[NMAX];  // column `lane`
-    u64 myz = 0;                // zeros of row `lane`
+    int myz = 0;       // zeros of row `lane` (bit j = column j)
+    unsigned zt = 0;   // zeros of column `lane` (bit i = row i)
     {
         const int cl = lane < n ? lane : 0;
 #pragma unroll
@@ -745,53 +781,59 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
             const double v = S.Cm[(i < n ? i : 0) * MLD + cl];
             col[i] = (i < n && lane < n) ? v : 1.0;
         }
-#pragma unroll
-        for (int i = 0; i < NMAX; ++i)
+        mk_for<NMAX>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
             if (i < n) {
-                const u64 m = __ballot(lane < n && col[i] == 0.0);
-                if (lane == i) myz = m;
+                const bool z = lane < n && col[i] == 0.0;
+                myz = writelane_const<i>((int)(unsigned)__ballot(z), myz);
+                zt |= z ? (1u << i) : 0u;
             }
+        });
     }
     int starcol = -1, primecol = -1;  // of row `lane`
-    u64 ccm = 0, rcm = 0;             // covered columns / rows
+    unsigned ccm = 0, rcm = 0;        // covered columns / rows
     // step 2: star the first zero of each row whose column has no star yet
     for (int i = 0; i < n; ++i) {
-        const u64 z = readlane_u64(myz, i) & ~ccm;
+        const unsigned z = readlane_u32((unsigned)myz, i) & ~ccm;
         if (z) {
-            const int j = __builtin_ctzll(z);
-            if (lane == i) starcol = j;
-            ccm |= 1ull << j;
+            const int j = __builtin_ctz(z);
+            starcol = setlane_i32(j, i, starcol, lane);
+            ccm |= 1u << j;
         }
     }
     ccm = 0;
     int step = 3, z0r = 0, z0c = 0;
     for (int guard = 0; guard < 200000; ++guard) {
         if (step == 3) {  // cover every column that holds a star
-            u64 rows = __ballot(starcol >= 0);
+            unsigned rows = (unsigned)__ballot(starcol >= 0);
             while (rows) {
-                const int i = __builtin_ctzll(rows);
+                const int i = __builtin_ctz(rows);
                 rows &= rows - 1;
-                ccm |= 1ull << __builtin_amdgcn_readlane(starcol, i);
+                ccm |= 1u << __builtin_amdgcn_readlane(starcol, i);
             }
-            if (__popcll(ccm) >= n) { star = starcol; return 0; }
+            if (__popc(ccm) >= n) { star = starcol; return 0; }
             step = 4;
         } else if (step == 4) {
             int row = 0, colc = 0;
+            // rows that hold an uncovered zero (their own cover aside): inside this step columns only get UNcovered, so the set
+            // only grows -- by the rows with a zero in the column that was uncovered
+            unsigned nz = (unsigned)__ballot(lane < n && ((unsigned)myz & ~ccm) != 0u);
             for (;;) {
                 // first uncovered row (cyclic from `row`) with an uncovered zero; in it the last uncovered zero in cyclic
                 // column order starting at `colc`
-                const u64 rows = __ballot(lane < n && !((rcm >> lane) & 1) && (myz & ~ccm) != 0);
+                const unsigned rows = nz & ~rcm;
                 if (!rows) { step = 6; break; }
-                const u64 hi = rows & ~((1ull << row) - 1ull);
-                const int fr = __builtin_ctzll(hi ? hi : rows);
-                const u64 unc = readlane_u64(myz, fr) & ~ccm;
-                const u64 low = unc & ((1ull << colc) - 1ull);
-                const int fc = 63 - __builtin_clzll(low ? low : unc);
-                if (lane == fr) primecol = fc;
+                const unsigned hi = rows & ~((1u << row) - 1u);
+                const int fr = __builtin_ctz(hi ? hi : rows);
+                const unsigned unc = readlane_u32((unsigned)myz, fr) & ~ccm;
+                const unsigned low = unc & ((1u << colc) - 1u);
+                const int fc = 31 - __builtin_clz(low ? low : unc);
+                primecol = setlane_i32(fc, fr, primecol, lane);
                 const int sc = __builtin_amdgcn_readlane(starcol, fr);
                 if (sc >= 0) {
-                    rcm |= 1ull << fr;
-                    ccm &= ~(1ull << sc);
+                    rcm |= 1u << fr;
+                    ccm &= ~(1u << sc);
+                    nz |= readlane_u32(zt, sc);
                     row = fr; colc = sc;
                 } else {
                     z0r = fr; z0c = fc; step = 5;
@@ -802,35 +844,44 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
             const int oldstar = starcol;
             int r = z0r, c = z0c;
             for (int hop = 0; hop <= HH_MAX_PEOPLE; ++hop) {
-                const u64 sm = __ballot(oldstar == c);  // the star of column c before the flips
-                if (lane == r) starcol = c;
+                const unsigned sm = (unsigned)__ballot(oldstar == c);  // the star of column c before the flips
+                starcol = setlane_i32(c, r, starcol, lane);
                 if (!sm) break;
-                r = __builtin_ctzll(sm);
+                r = __builtin_ctz(sm);
                 c = __builtin_amdgcn_readlane(primecol, r);
             }
             rcm = 0; ccm = 0; primecol = -1;
             step = 3;
         } else {  // step 6: smallest uncovered value; add it to covered rows, subtract it from uncovered columns
             double mn = 9223372036854775807.0;
-            const bool cu = lane < n && !((ccm >> lane) & 1);
+            const bool colunc = !((ccm >> (lane & 31)) & 1u);
+            const bool cu = lane < n && colunc;
 #pragma unroll
             for (int i = 0; i < NMAX; ++i)
-                if (i < n && cu && !((rcm >> i) & 1) && mn > col[i]) mn = col[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double o = __shfl_xor(mn, off);
-                mn = o < mn ? o : mn;
+                if (i < n && cu && !((rcm >> i) & 1u) && mn > col[i]) mn = col[i];
+            {   // minimum over lanes 0 .. 31 (the others hold the start value): four rotations inside the 16-lane rows, then the two rows
+                double o;
+                o = row_ror_f64<1>(mn); mn = o < mn ? o : mn;
+                o = row_ror_f64<2>(mn); mn = o < mn ? o : mn;
+                o = row_ror_f64<4>(mn); mn = o < mn ? o : mn;
+                o = row_ror_f64<8>(mn); mn = o < mn ? o : mn;
+                const double m0 = readlane_f64(mn, 0), m1 = readlane_f64(mn, 16);
+                mn = m1 < m0 ? m1 : m0;
             }
-#pragma unroll
-            for (int i = 0; i < NMAX; ++i)
+            unsigned ztn = 0;
+            mk_for<NMAX>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 if (i < n) {
                     double c = col[i];
-                    if ((rcm >> i) & 1) c += mn;
-                    if (!((ccm >> lane) & 1)) c -= mn;
+                    if ((rcm >> i) & 1u) c += mn;
+                    if (colunc) c -= mn;
                     col[i] = c;
-                    const u64 m = __ballot(lane < n && c == 0.0);
-                    if (lane == i) myz = m;
+                    const bool z = lane < n && c == 0.0;
+                    myz = writelane_const<i>((int)(unsigned)__ballot(z), myz);
+                    ztn |= z ? (1u << i) : 0u;
                 }
+            });
+            zt = ztn;
             step = 4;
         }
     }
@@ -844,6 +895,24 @@ __device__ __forceinline__ int munkres_wave(MatchShared &S, int n, int lane, int
     if (n <= 16) return munkres_wave_n<16>(S, n, lane, star);
     if (n <= 24) return munkres_wave_n<24>(S, n, lane, star);
     return munkres_wave_n<HH_MAX_PEOPLE>(S, n, lane, star);
+}
+
+// the solver alone on one square float64 matrix (tests: the reference's pinned munkres goldens through the GPU step machine)
+__global__ __launch_bounds__(64) void munkres_debug_kernel(const double *__restrict__ cost, int n, int32_t *__restrict__ out)
+{
+    __shared__ MatchShared S;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n * n; i += 64) S.Cm[(i / n) * MLD + i % n] = cost[i];
+    __syncthreads();
+    int star = -1;
+    const int bad = munkres_wave(S, n, lane, star);
+    if (lane < n) out[lane] = star;
+    if (lane == 0) out[n] = bad;
+}
+hipError_t launch_munkres_debug(const double *cost, int n, int32_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(munkres_debug_kernel, dim3(1), dim3(64), 0, s, cost, n, out);
+    return hipGetLastError();
 }
 
 __constant__ int c_joints_order[17] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 7, 8, 9, 10, 13, 14, 15, 16};  // grouping.py:63-65

@@ -147,6 +147,24 @@ int hh_resize_accumulate(const float *src, int64_t src_bstride, int B, int K, in
     return 0;
 }
 
+int hh_debug_munkres(const double *cost, int n, int32_t *star)
+{
+    if (!cost || !star || n <= 0 || n > HH_MAX_PEOPLE) { hh_set_error("hh_debug_munkres: need 0 < n <= 32"); return 1; }
+    double *d_cost = nullptr;
+    int32_t *d_out = nullptr;
+    HH_CHECK_HIP(hipMalloc((void **)&d_cost, (size_t)n * n * 8));
+    if (hipMalloc((void **)&d_out, (size_t)(n + 1) * 4) != hipSuccess) { hipFree(d_cost); hh_set_error("hh_debug_munkres: hipMalloc"); return 1; }
+    std::vector<int32_t> out(n + 1, -2);
+    hipError_t e = hipMemcpy(d_cost, cost, (size_t)n * n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_munkres_debug(d_cost, n, d_out, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost);
+    hipFree(d_cost); hipFree(d_out);
+    HH_CHECK_HIP(e);
+    if (out[n]) { hh_set_error("hh_debug_munkres: the solver hit its iteration guard"); return 1; }
+    for (int i = 0; i < n; ++i) star[i] = out[i];
+    return 0;
+}
+
 int hh_decoder_read_topk(hh_decoder *dec, float *tags_k, int32_t *coords_k, float *scores_k)
 {
     if (!dec->lastB) { hh_set_error("hh_decoder_read_topk: nothing decoded yet"); return 1; }

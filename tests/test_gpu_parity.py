@@ -352,6 +352,44 @@ def test_decode_bit_exact_vs_reference_golden(pkg, synth, decode_golden):
             assert np.array_equal(sk[0][pos], g[tag + "/scores_k"][pos]) and np.array_equal(ck[0][pos], g[tag + "/coords_k"][pos])
 
 
+def test_gpu_assignment_solver_vs_pinned_munkres(pkg):
+    """The matcher's step machine alone (hh_debug_munkres: one wavefront, 32-bit zero / cover masks, per-column zero masks that keep
+    step 4's row set up to date): the 60 matrices whose assignments munkres 1.1.4 itself wrote (tests/golden/munkres.npz; rectangular
+    ones padded with zeros as munkres.pad_matrix does), then 300 seeded square problems with many equal entries -- the
+    `round(dist) * 100 - score` costs of grouping.py:121-125 tie often, and WHICH zero is starred first is the contract -- against
+    the C restatement that those goldens pin."""
+    import ctypes as C
+    lib = pkg._lib.load()
+
+    def solve(cost):
+        r, c = cost.shape
+        n = max(r, c)
+        sq = np.zeros((n, n), np.float64)
+        sq[:r, :c] = cost
+        star = np.full(n, -9, np.int32)
+        assert lib.hh_debug_munkres(sq.ctypes.data_as(C.POINTER(C.c_double)), n, star.ctypes.data_as(C.POINTER(C.c_int32))) == 0, lib.hh_last_error().decode()
+        return np.array([(i, star[i]) for i in range(r) if 0 <= star[i] < c], np.int32).reshape(-1, 2)
+
+    d = np.load(os.path.join(GOLDEN, "munkres.npz"))
+    for i in range(len(d.files) // 2):
+        assert np.array_equal(solve(d[f"m{i}"]), d[f"r{i}"]), f"golden {i} {d[f'm{i}'].shape}"
+    rng = np.random.default_rng(77)
+    for t in range(300):
+        n = int(rng.integers(1, 33))
+        kind = t % 4
+        if kind == 0:
+            cost = rng.integers(0, 4, (n, n)).astype(np.float64) * 100.0 - rng.integers(0, 3, (n, n)) * 0.25  # few distinct values
+        elif kind == 1:
+            cost = np.round(rng.uniform(0, 3, (n, n))) * 100.0 - rng.uniform(0.05, 1.0, (n, 1)).astype(np.float32).astype(np.float64)
+        elif kind == 2:
+            cost = rng.uniform(0, 5, (n, n))
+            cost[:, rng.integers(0, n, max(1, n // 3))] = 1e10  # the reference's padding columns (grouping.py:126-128)
+        else:
+            cost = np.zeros((n, n))  # everything ties
+            cost[rng.integers(0, n, n), rng.integers(0, n, n)] = 1.0
+        assert np.array_equal(solve(cost), orc.munkres(cost)), (t, n, kind)
+
+
 def test_decode_fuzz_vs_oracle(pkg, synth):
     """Seeded sweep beside the 14 reference goldens: 48 constructed cases over ragged map sizes, 0..30 people (more candidates
     than `max_people` included), one and two embedding maps (flip TTA), both threshold pairs the reference uses (inference

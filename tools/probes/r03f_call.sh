@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-K="decode or parse or end_to_end or chained or validation or infer_images or evaluate or native or full_size"
+K="decode or parse or end_to_end or chained or validation or infer_images or evaluate or native or full_size or assignment"
 timeout -k 10 800 python -m pytest tests -m gpu -x -q -p no:cacheprovider -k "$K" > gpurun_out/f1_test.log 2>&1
 rc=$?; tail -6 gpurun_out/f1_test.log
 [ $rc -ne 0 ] && exit $rc
