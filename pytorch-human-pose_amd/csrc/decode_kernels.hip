@@ -742,6 +742,8 @@ __device__ __forceinline__ double row_ror_f64(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x120 + ROT, 0xf, 0xf, false);
     return __builtin_bit_cast(double, ((u64)(unsigned)hi << 32) | (u64)(unsigned)lo);
 }
+template <int ROT>
+__device__ __forceinline__ unsigned row_ror_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + ROT, 0xf, 0xf, false); }
 __device__ __forceinline__ double readlane_f64(double v, int l)
 {
     const u64 b = __builtin_bit_cast(u64, v);
@@ -771,6 +773,7 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
         for (int j = 0; j < NMAX; ++j) if (j < n) S.Cm[lane * MLD + j] = rowv[j] - mn;
     }
     __syncthreads();
+    const unsigned nmask = n >= 32 ? 0xffffffffu : (1u << n) - 1u;  // lanes / rows / columns of the problem
     double col[NMAX];  // column `lane`
     int myz = 0;       // zeros of row `lane` (bit j = column j)
     unsigned zt = 0;   // zeros of column `lane` (bit i = row i)
@@ -784,8 +787,9 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
         mk_for<NMAX>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if (i < n) {
-                const bool z = lane < n && col[i] == 0.0;
-                myz = writelane_const<i>((int)(unsigned)__ballot(z), myz);
+                // (lanes >= n hold 1.0 and are masked out of the ballot; their own `zt` is never read)
+                const bool z = col[i] == 0.0;
+                myz = writelane_const<i>((int)((unsigned)__ballot(z) & nmask), myz);
                 zt |= z ? (1u << i) : 0u;
             }
         });
@@ -805,12 +809,11 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
     int step = 3, z0r = 0, z0c = 0;
     for (int guard = 0; guard < 200000; ++guard) {
         if (step == 3) {  // cover every column that holds a star
-            unsigned rows = (unsigned)__ballot(starcol >= 0);
-            while (rows) {
-                const int i = __builtin_ctz(rows);
-                rows &= rows - 1;
-                ccm |= 1u << __builtin_amdgcn_readlane(starcol, i);
-            }
+            // (an OR over the lanes' star bits -- four row rotations and the two rows of lanes 0 .. 31 -- instead of one lane read per
+            // starred row: this step runs once per augmentation, ~50 times per dense problem)
+            unsigned x = starcol >= 0 ? (1u << starcol) : 0u;
+            x |= row_ror_u32<1>(x); x |= row_ror_u32<2>(x); x |= row_ror_u32<4>(x); x |= row_ror_u32<8>(x);
+            ccm |= readlane_u32(x, 0) | readlane_u32(x, 16);
             if (__popc(ccm) >= n) { star = starcol; return 0; }
             step = 4;
         } else if (step == 4) {
@@ -818,6 +821,9 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
             // rows that hold an uncovered zero (their own cover aside): inside this step columns only get UNcovered, so the set
             // only grows -- by the rows with a zero in the column that was uncovered
             unsigned nz = (unsigned)__ballot(lane < n && ((unsigned)myz & ~ccm) != 0u);
+            // (the column cover as a scalar inside the loop: the compiler keeps `ccm` in a vector register -- steps 4's ballot and 6
+            // use it per lane -- and would run the bit scans below through the vector pipe)
+            unsigned cs = (unsigned)__builtin_amdgcn_readfirstlane((int)ccm);
             for (;;) {
                 // first uncovered row (cyclic from `row`) with an uncovered zero; in it the last uncovered zero in cyclic
                 // column order starting at `colc`
@@ -825,14 +831,14 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
                 if (!rows) { step = 6; break; }
                 const unsigned hi = rows & ~((1u << row) - 1u);
                 const int fr = __builtin_ctz(hi ? hi : rows);
-                const unsigned unc = readlane_u32((unsigned)myz, fr) & ~ccm;
+                const unsigned unc = readlane_u32((unsigned)myz, fr) & ~cs;
                 const unsigned low = unc & ((1u << colc) - 1u);
                 const int fc = 31 - __builtin_clz(low ? low : unc);
                 primecol = setlane_i32(fc, fr, primecol, lane);
                 const int sc = __builtin_amdgcn_readlane(starcol, fr);
                 if (sc >= 0) {
                     rcm |= 1u << fr;
-                    ccm &= ~(1u << sc);
+                    cs &= ~(1u << sc);
                     nz |= readlane_u32(zt, sc);
                     row = fr; colc = sc;
                 } else {
@@ -840,6 +846,7 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
                     break;
                 }
             }
+            ccm = cs;
         } else if (step == 5) {  // alternate primes and stars from the uncovered prime: each row on the path takes its prime
             const int oldstar = starcol;
             int r = z0r, c = z0c;
@@ -869,15 +876,19 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
                 mn = m1 < m0 ? m1 : m0;
             }
             unsigned ztn = 0;
+            // munkres.py:303-309 adds the minimum to covered rows and then subtracts it from uncovered columns: two roundings in that
+            // order where both apply.  Written as c + a_i - sub with a_i = mn or 0 (wave-uniform: the row's cover) and sub = mn or 0
+            // (the lane's column): adding or subtracting 0.0 returns c itself (up to the sign of a zero, which nothing here looks at),
+            // and the selects act on one scalar and one register instead of on every element.
+            const double sub = colunc ? mn : 0.0;
             mk_for<NMAX>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if (i < n) {
-                    double c = col[i];
-                    if ((rcm >> i) & 1u) c += mn;
-                    if (colunc) c -= mn;
+                    const double a_i = ((rcm >> i) & 1u) ? mn : 0.0;
+                    const double c = (col[i] + a_i) - sub;
                     col[i] = c;
-                    const bool z = lane < n && c == 0.0;
-                    myz = writelane_const<i>((int)(unsigned)__ballot(z), myz);
+                    const bool z = c == 0.0;
+                    myz = writelane_const<i>((int)((unsigned)__ballot(z) & nmask), myz);
                     ztn |= z ? (1u << i) : 0u;
                 }
             });

@@ -11,3 +11,4 @@ for i in 1 2 3; do
   echo "this lib : $(timeout -k 10 100 python tools/decode_time.py 2>/dev/null | tail -1)   dense $(HH_DECODE_PEOPLE=27 timeout -k 10 100 python tools/decode_time.py 2>/dev/null | tail -1)"
 done | tee gpurun_out/f1_decode.log
 bash tools/probes/decode_kstats.sh 2>&1 | grep -v amdgpu.ids | tee gpurun_out/f1_kstats.log
+bash tools/probes/decode_kstats.sh dense 2>&1 | grep -v amdgpu.ids | tee gpurun_out/f1_kstats_dense.log
