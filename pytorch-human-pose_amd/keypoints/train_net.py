@@ -10,6 +10,8 @@ DistributedDataParallel (gradient all-reduce over RCCL) work on the module uncha
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
@@ -17,25 +19,40 @@ from torch import Tensor, nn
 from . import train_ops as ops
 
 
+class _ResBox:
+    """The gradient a residual unit's skip connection carries (hrnet.py:62-74,108-124: `out += identity`), handed from the last
+    BatchNorm's backward straight to the first conv's: that conv's data-gradient launch starts its accumulators from it (the
+    residual input of the conv kernels), so dL/dx = conv1's data gradient + skip gradient is rounded to bf16 once and autograd's
+    separate elementwise add per unit (111 launches per step) is gone.  The unit's backward always runs bn_last -> ... -> conv1."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: Tensor, w: Tensor, stride: int, pad, packed_fwd=None, packed_bwd=None):
+    def forward(ctx, x: Tensor, w: Tensor, stride: int, pad, packed_fwd=None, packed_bwd=None, box=None):
         ctx.save_for_backward(x, w)
-        ctx.stride, ctx.pad, ctx.packed_bwd = stride, pad, packed_bwd
+        ctx.stride, ctx.pad, ctx.packed_bwd, ctx.box = stride, pad, packed_bwd, box
         return ops.conv2d(x, w, stride, pad=pad, packed=packed_fwd)
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         x, w = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dx = ops.conv2d(dy, w, ctx.stride, data_grad=True, pad=ctx.pad, packed=ctx.packed_bwd) if ctx.needs_input_grad[0] else None
+        skip = None
+        if ctx.box is not None:  # the unit's skip gradient (left there by its last BatchNorm's backward, which has run)
+            skip, ctx.box.g = ctx.box.g, None
+        dx = ops.conv2d(dy, w, ctx.stride, data_grad=True, pad=ctx.pad, packed=ctx.packed_bwd, res=skip) if ctx.needs_input_grad[0] else None
         dw = ops.conv2d_weight_grad(x, dy, w.shape[-1], ctx.stride, pad=ctx.pad) if ctx.needs_input_grad[1] else None
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 class _BNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, res, relu: bool, eps: float, stats: list):
+    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, res, relu: bool, eps: float, stats: list, box=None):
+        ctx.box = box  # not None: the residual's gradient goes into the box (for the unit's first conv), not back through autograd
         ctx.sync = _sync_world()
         if ctx.sync is not None:  # SyncBatchNorm: statistics over every rank's pixels
             y, mean, invstd, ctx.count = ops.sync_bn_train_forward(x, gamma, beta, eps, res, relu, *ctx.sync)
@@ -53,10 +70,14 @@ class _BNFn(torch.autograd.Function):
         if ctx.sync is not None:
             dx, dgamma, dbeta, dres = ops.sync_bn_train_backward(x, y, dy.contiguous(memory_format=torch.channels_last), mean, invstd,
                                                                  gamma, ctx.relu, ctx.has_res, ctx.sync[0], ctx.count)
-            return dx, dgamma, dbeta, dres, None, None, None
+            if ctx.box is not None:
+                ctx.box.g, dres = dres, None
+            return dx, dgamma, dbeta, dres, None, None, None, None
         dx, dgamma, dbeta, dres = ops.bn_train_backward(x, y, dy.contiguous(memory_format=torch.channels_last), mean, invstd, gamma,
                                                         ctx.relu, want_dres=ctx.has_res)
-        return dx, dgamma, dbeta, dres, None, None, None
+        if ctx.box is not None:
+            ctx.box.g, dres = dres, None
+        return dx, dgamma, dbeta, dres, None, None, None, None
 
 
 class _FusionSumFn(torch.autograd.Function):
@@ -80,7 +101,7 @@ def _pad_c(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
-def conv(x: Tensor, m: nn.Conv2d, stride: int | None = None) -> Tensor:
+def conv(x: Tensor, m: nn.Conv2d, stride: int | None = None, box: _ResBox | None = None) -> Tensor:
     """nn.Conv2d forward on the HIP kernels.  Channel counts the kernels cannot take (3, 17, 34, 66 ...) are zero padded:
     padding and slicing are differentiable torch ops, so the gradients reach the unpadded parameter."""
     w = m.weight
@@ -92,7 +113,9 @@ def conv(x: Tensor, m: nn.Conv2d, stride: int | None = None) -> Tensor:
     if x.shape[1] != cin_p:
         x = F.pad(x, (0, 0, 0, 0, 0, cin_p - x.shape[1]))
     pk = _PACKED[0].get((id(m.weight), stride)) if (_PACKED[0] is not None and w is m.weight) else None
-    y = _ConvFn.apply(x.contiguous(memory_format=torch.channels_last), w, stride, None, *(pk if pk is not None else (None, None)))
+    if box is not None and (cin_p != cin or x.shape[1] != cin):
+        raise ValueError("conv: a skip-gradient box needs an unpadded input")
+    y = _ConvFn.apply(x.contiguous(memory_format=torch.channels_last), w, stride, None, *(pk if pk is not None else (None, None)), box)
     if cout_p != cout:
         y = y[:, :cout]
     if m.bias is not None:
@@ -142,12 +165,12 @@ def _sync_world():
 _PENDING_STATS: list = []  # (module, batch mean, batch invstd, pixels) of the forward in flight, applied by flush_running_stats
 
 
-def bn(x: Tensor, m: nn.BatchNorm2d, relu: bool = False, res: Tensor | None = None) -> Tensor:
+def bn(x: Tensor, m: nn.BatchNorm2d, relu: bool = False, res: Tensor | None = None, box: _ResBox | None = None) -> Tensor:
     """nn.BatchNorm2d in training mode (+ residual, + ReLU); the running statistics are updated like torch updates them,
     once per forward for all layers together (flush_running_stats)."""
     stats: list = []
     y = _BNFn.apply(x.contiguous(memory_format=torch.channels_last), m.weight, m.bias,
-                    res.contiguous(memory_format=torch.channels_last) if res is not None else None, relu, m.eps, stats)
+                    res.contiguous(memory_format=torch.channels_last) if res is not None else None, relu, m.eps, stats, box)
     if m.track_running_stats and m.running_mean is not None:
         _PENDING_STATS.append((m, stats[0][0], stats[0][1], stats[0][2]))  # count = pixels of all ranks under SyncBatchNorm
     return y
@@ -206,17 +229,26 @@ def deconv_k4s2(x: Tensor, m: nn.ConvTranspose2d) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------ the net
+_NO_RESBOX = bool(os.environ.get("HH_TRAIN_NO_RESBOX"))  # A/B: the skip gradients through autograd's own accumulation
+
+
+def _boxable(x, c: nn.Conv2d) -> bool:
+    return not _NO_RESBOX and x.requires_grad and c.weight.shape[1] % 16 == 0 and x.shape[1] == c.weight.shape[1]
+
+
 def _bottleneck(x, u):
-    y = bn(conv(x, u.conv1), u.bn1, relu=True)
-    y = bn(conv(y, u.conv2), u.bn2, relu=True)
     ds = u._modules.get("downsample")
+    box = _ResBox() if ds is None and _boxable(x, u.conv1) else None  # identity skip: its gradient joins conv1's data gradient
+    y = bn(conv(x, u.conv1, box=box), u.bn1, relu=True)
+    y = bn(conv(y, u.conv2), u.bn2, relu=True)
     r = bn(conv(x, ds._modules["0"]), ds._modules["1"]) if ds is not None else x
-    return bn(conv(y, u.conv3), u.bn3, relu=True, res=r)
+    return bn(conv(y, u.conv3), u.bn3, relu=True, res=r, box=box)
 
 
 def _basic(x, u):
-    y = bn(conv(x, u.conv1), u.bn1, relu=True)
-    return bn(conv(y, u.conv2), u.bn2, relu=True, res=x)
+    box = _ResBox() if _boxable(x, u.conv1) else None
+    y = bn(conv(x, u.conv1, box=box), u.bn1, relu=True)
+    return bn(conv(y, u.conv2), u.bn2, relu=True, res=x, box=box)
 
 
 def _children(m):

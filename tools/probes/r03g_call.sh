@@ -7,6 +7,6 @@ rc=$?; tail -6 gpurun_out/g1_test.log
 [ $rc -ne 0 ] && exit $rc
 tr() { timeout -k 10 300 python bench.py --train --steps 20 --warmup 5 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"; }
 for i in 1 2; do
-  echo "prev lib: $(HH_LIB=$PWD/scratch/libhhrnet_prev.so tr)"
-  echo "this lib: $(tr)"
+  echo "autograd adds: $(HH_TRAIN_NO_RESBOX=1 tr)"
+  echo "skip boxes   : $(tr)"
 done | tee gpurun_out/g1_train.log
