@@ -2,10 +2,12 @@
 #define HH_NMS_DEBUG 1
 #include "../../pytorch-human-pose_amd/csrc/decode_kernels.hip"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
-int main()
+int main(int argc, char **argv)
 {
+    const float thr = argc > 1 ? (float)atof(argv[1]) : 0.f;  // tile-skipping threshold (0.05 = the bench's det_thr: most tiles leave early)
     const int B = 32, K = 17, H = 512, W = 512, M = 30;
     DecodeSrc src{};
     src.mode = 0; src.B = B; src.K = K; src.H = H; src.W = W; src.E = 1;
@@ -25,9 +27,9 @@ int main()
     unsigned long long *ck; float *cv, *cm;
     hipMalloc(&ck, (size_t)B * K * nt * M * 8); hipMalloc(&cv, (size_t)B * K * nt * M * 4); hipMalloc(&cm, (size_t)B * K * (H / 4) * (W / 4) * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) launch_nms_tile_topk(src, M, ck, cv, cm, 0);
+    for (int i = 0; i < 3; ++i) launch_nms_tile_topk(src, M, ck, cv, cm, thr, 0);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 10; ++i) launch_nms_tile_topk(src, M, ck, cv, cm, 0);
+    for (int i = 0; i < 10; ++i) launch_nms_tile_topk(src, M, ck, cv, cm, thr, 0);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("nms kernel %.1f us per launch, %d tiles per map\n", ms * 100.f, nt);
@@ -36,9 +38,11 @@ int main()
     double sum[8] = {}; int cnt = 0;
     for (int w = 0; w < 4 * nt && w < 4096; ++w) {
         const long long *r = &d[w * 8];
-        if (r[0] == 0 || r[6] <= r[0]) continue;
+        // (with tile skipping on, an active tile leaves behind stamp 5 and an inactive one behind stamp 1: count the tiles that got
+        // at least through the compaction, phase by phase up to their last stamp)
+        if (r[0] == 0 || r[5] <= r[0]) continue;
         ++cnt;
-        for (int i = 1; i <= 6; ++i) sum[i] += (double)(r[i] - r[i - 1]);
+        for (int i = 1; i <= 6 && r[i] > r[i - 1]; ++i) sum[i] += (double)(r[i] - r[i - 1]);
     }
     const char *nm[] = {"", "pass A (global->hrow)", "pass B (v)", "cellmax + row pass", "col pass", "nv + compaction", "rank + zeros"};
     double tot = 0;
