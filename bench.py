@@ -428,7 +428,6 @@ def main():
                      105: "bb_fp8_kernel (fused e4m3 BasicBlock: conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU)",
                      103: "bb64_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=64)",
                      102: "stem_conv_kernel (fp32 NCHW -> conv3x3 s2 3->64 + BN + ReLU -> bf16 NHWC)",
-                     107: "conv3x3_m16_kernel (3x3 s1, v_mfma_f32_16x16x32_bf16; HH_CONV_M16 experiment)",
                      106: "stem_fused_kernel (fp32 NCHW -> conv3x3 s2 3->64 + BN + ReLU -> conv3x3 s2 64->64 + BN + ReLU -> bf16 NHWC)",
                      101: "junction_kernel (stage-0 conv3 1x1 [+downsample] + residual + ReLU + next conv1 1x1 + ReLU)"}
             kname = kernel_name(dom)

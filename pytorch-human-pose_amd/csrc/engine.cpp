@@ -32,7 +32,6 @@ PlanSwitches PlanSwitches::from_env()
     s.poison_lds = on("HH_POISON_LDS");
     s.no_head_fold = on("HH_NO_HEAD_FOLD");
     s.no_conv_db = on("HH_NO_CONV_DB");
-    s.conv_m16 = on("HH_CONV_M16");
     if (const char *fc = getenv("HH_FAT_CUS")) { s.fat_cus = s.fat_cus64 = atoi(fc); if (const char *c2 = strchr(fc, ',')) s.fat_cus64 = atoi(c2 + 1); }
     if (const char *sk = getenv("HH_DEBUG_SKIP")) {
         static const struct { const char *name; unsigned bit; } cats[] = {{"s2big", SK_S2BIG}, {"s2", SK_S2}, {"upadd", SK_UPADD}, {"c1x1", SK_C1X1},
@@ -640,7 +639,6 @@ int hh_net::finalize()
     for (auto &p : params)
         if (!p.loaded && !p.counter) { hh_set_error("hh_finalize: parameter never loaded: " + p.name); return 1; }
     HH_CHECK_HIP(conv_init());
-    HH_CHECK_HIP(conv3x3_m16_init());
     HH_CHECK_HIP(bb_fused_init());
     HH_CHECK_HIP(stem_fused_init());
     HH_CHECK_HIP(bbpc_init());
@@ -689,10 +687,6 @@ int hh_net::finalize()
         l.db = !sw.no_conv_db && !l.stem2 && l.ks == 3 && l.stride == 1 && !l.transposed && l.mconv.empty() && l.cin >= 128 &&
                l.cin % 16 == 0 && coutp % 64 == 0;
         if (l.db) { l.KC = 16; l.NT = 2; }
-        // experiment (conv3x3_m16.hip): the same layers on v_mfma_f32_16x16x32_bf16, from the KC = 32 weight image
-        l.m16 = sw.conv_m16 && !l.stem2 && l.ks == 3 && l.stride == 1 && !l.transposed && l.mconv.empty() && l.cin >= 128 &&
-                l.cin % 32 == 0 && coutp % 64 == 0;
-        if (l.m16) { l.db = 0; l.KC = 32; l.NT = 2; }
         l.cin_pad = round_up(l.cin, l.KC);
         const int COUT_T = 32 * l.NT;
         l.ncg = coutp / COUT_T;
@@ -1252,10 +1246,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 }
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
             }
-            if (l.m16 && p.Wo > 16 && conv3x3_m16_supported(p)) {  // (16-wide maps: the TW = 16 instantiation of the KC = 32 family)
-                if (pr) pr->cfg = HH_CFG_M16;
-                HH_CHECK_HIP(conv3x3_m16_launch(p, s));
-            } else HH_CHECK_HIP(conv_launch(cfg, p, s));
+            HH_CHECK_HIP(conv_launch(cfg, p, s));
             break;
         }
         }

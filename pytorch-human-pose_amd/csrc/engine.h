@@ -49,7 +49,6 @@ struct ConvLayer {
     size_t phase_stride = 0;
     // chosen at finalize
     int KC = 0, NT = 0, cin_pad = 0, ncg = 0;
-    int m16 = 0; // 1: conv3x3_m16.hip (PlanSwitches::conv_m16)
     int db = 0;  // 1: the double-buffered instantiation (3x3 stride 1, >= 128 input channels; PlanSwitches::no_conv_db)
     bf16_raw *d_w = nullptr;
     float *d_bias = nullptr;
@@ -145,7 +144,6 @@ struct PlanSwitches {
     // lanes find free CUs while either runs: forward 4.48 -> 4.39 ms, +1.5-2 % img/s (three alternations, profiles/r03_ab.md).
     // HH_FAT_CUS=n[,m] sets them (256 = one per CU, the round-2 plan); a quarter of the chip for the 64-channel block loses 6 %.
     int fat_cus = 0, fat_cus64 = 0;
-    bool conv_m16 = false;         // HH_CONV_M16=1 (experiment): those convs on the 16x16x32 MFMA shape (conv3x3_m16.hip)
     bool no_conv_db = false;       // HH_NO_CONV_DB=1: the 128- / 256-channel 3x3 convs on the single-buffer KC = 32 instantiations (round 2)
     bool no_head_fold = false;     // HH_NO_HEAD_FOLD=1: init_heatmaps_head writes its output into the concat buffer, the transposed conv reads it
     bool poison_lds = false;       // HH_POISON_LDS=1 (tests): every CU's LDS filled with NaN patterns in front of every launch

@@ -76,12 +76,6 @@ const ConvConfig &conv_config(int i);
 hipError_t conv_launch(int cfg_index, const ConvParams &p, hipStream_t stream);
 hipError_t conv_init();  // raises the dynamic-LDS limit of every instantiation
 
-// ---- conv3x3_m16.hip (experiment, PlanSwitches::conv_m16): 3x3 stride 1 on v_mfma_f32_16x16x32_bf16, KC = 32 / NT = 2 weight image
-#define HH_CFG_M16 107  // pseudo instantiation index used by the profiler
-bool conv3x3_m16_supported(const ConvParams &p);
-hipError_t conv3x3_m16_launch(ConvParams p, hipStream_t stream);
-hipError_t conv3x3_m16_init();
-
 // ---- fp8 path (conv_fp8.hip): e4m3 NHWC activations with one scale per tensor, e4m3 weights with one scale per cout
 struct Fp8ConvParams {
     const unsigned char *in;  // [B, Hin, Win, in_cs] e4m3

@@ -188,8 +188,7 @@ def test_schedule_and_fusion_switches(pkg, net_golden):
     x = torch.from_numpy(pkg.synth.synth_images(2, 128, 128, 1)).to(DEV)
     base, _ = _net(pkg, 32, 1)
     ref = [t.clone() for t in base.forward_raw(x)]
-    for env, exact in ((("HH_FULL_JOIN", "1"), True), (("HH_NO_FUSION_MERGE", "1"), False), (("HH_NO_JUNC_PAIR", "1"), True), (("HH_NO_CONV_DB", "1"), False),
-                       (("HH_CONV_M16", "1"), False)):
+    for env, exact in ((("HH_FULL_JOIN", "1"), True), (("HH_NO_FUSION_MERGE", "1"), False), (("HH_NO_JUNC_PAIR", "1"), True), (("HH_NO_CONV_DB", "1"), False)):
         os.environ[env[0]] = env[1]
         try:
             net, _ = _net(pkg, 32, 1)
