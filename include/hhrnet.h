@@ -228,6 +228,9 @@ int hh_loss_ae_grouping(const float *tags, int64_t tags_bstride, const int32_t *
  *   variance, y = act(gamma * (x - mean) * invstd + beta (+ res)); mean / invstd are kept for the backward.
  *   scratch: 256 * C * 2 doubles.  (The running statistics are updated by the caller: plain torch arithmetic on C floats.)
  * hh_bn_train_backward: dx, dgamma, dbeta (and dres = the gradient after the ReLU mask, if dres != NULL).
+ * hh_bn_train_backward_plain: the same for a BatchNorm that had no residual input, without its stored output y: no ReLU needs
+ *   nothing of it, and with ReLU the mask y > 0 is recomputed from x (gamma * (x - mean) * invstd + beta > 0, evaluated by the
+ *   function the forward evaluated) -- one tensor pass less in each of the two kernels.
  * hh_conv2d_wgrad: dw [cout][cin][ks][ks] fp32 = dL/dW of y = conv(x, W) (padding (ks-1)/2) from x [B,H,W,cin] and
  *   dy [B,Ho,Wo,cout]; 3x3 stride 1/2 and 1x1 stride 1, channel counts % 8 == 0.  A GEMM contracted over pixels on MFMA
  *   (operands read from LDS with the transposing ds_read_b64_tr_b16), partial sums reduced in a fixed order.          */
@@ -252,6 +255,8 @@ int hh_bn_train_forward(const void *x, int64_t P, int C, const float *gamma, con
                         void *y, float *mean, float *invstd, double *scratch, void *stream);
 int hh_bn_train_backward(const void *x, const void *y, const void *dy, int64_t P, int C, const float *mean, const float *invstd,
                          const float *gamma, int relu, void *dx, void *dres, float *dgamma, float *dbeta, double *scratch, void *stream);
+int hh_bn_train_backward_plain(const void *x, const void *dy, int64_t P, int C, const float *mean, const float *invstd, const float *gamma,
+                               const float *beta, int relu, void *dx, float *dgamma, float *dbeta, double *scratch, void *stream);
 
 /* FusionLayer's sum in the training step (hrnet.py:214-229: `sum_j f_ij(x_j)` then ReLU, with nn.Upsample(nearest) on the
  * low-resolution terms, hrnet.py:200-205): out = act(sum_j term_j[b, y >> shift_j, x >> shift_j, :]) over 1..4 NHWC bf16

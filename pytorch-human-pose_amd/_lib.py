@@ -88,6 +88,7 @@ def _sig(lib):
         "hh_fusion_sum_backward": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
         "hh_bn_train_forward": (i32, [vp, i64, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, vp, vp]),
         "hh_bn_train_backward": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+        "hh_bn_train_backward_plain": (i32, [vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
         "hh_conv2d_packed_elems": (i64, [i32, i32, i32, i32, i32]),
         "hh_pack_conv_weights_batch": (i32, [i32, vp, vp, vp, vp, vp]),
         "hh_conv2d_packed": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),

@@ -400,7 +400,16 @@ int hh_bn_train_backward(const void *x, const void *y, const void *dy, int64_t P
 {
     if (!x || !y || !dy || !dx || !mean || !invstd || !gamma || !dgamma || !dbeta || !scratch || P <= 0 || C <= 0 || C % 8 || C > 2048) { hh_set_error("hh_bn_train_backward: bad argument"); return 1; }
     HH_CHECK_HIP(launch_bn_train_backward((const bf16_raw *)x, (const bf16_raw *)y, (const bf16_raw *)dy, C, (size_t)P, C, mean, invstd, gamma,
-                                          relu, (bf16_raw *)dx, (bf16_raw *)dres, dgamma, dbeta, scratch, (hipStream_t)stream));
+                                          nullptr, relu, (bf16_raw *)dx, (bf16_raw *)dres, dgamma, dbeta, scratch, (hipStream_t)stream));
+    return 0;
+}
+
+int hh_bn_train_backward_plain(const void *x, const void *dy, int64_t P, int C, const float *mean, const float *invstd, const float *gamma,
+                               const float *beta, int relu, void *dx, float *dgamma, float *dbeta, double *scratch, void *stream)
+{
+    if (!x || !dy || !dx || !mean || !invstd || !gamma || !beta || !dgamma || !dbeta || !scratch || P <= 0 || C <= 0 || C % 8 || C > 2048) { hh_set_error("hh_bn_train_backward_plain: bad argument"); return 1; }
+    HH_CHECK_HIP(launch_bn_train_backward((const bf16_raw *)x, nullptr, (const bf16_raw *)dy, C, (size_t)P, C, mean, invstd, gamma, beta, relu,
+                                          (bf16_raw *)dx, nullptr, dgamma, dbeta, scratch, (hipStream_t)stream));
     return 0;
 }
 

@@ -288,8 +288,8 @@ hipError_t launch_pack_weights(const float *W, int cout, int cin, int ks, int mo
 hipError_t launch_bn_train_forward(const bf16_raw *x, int cs, size_t P, int C, const float *gamma, const float *beta, float eps,
                                    const bf16_raw *res, int relu, bf16_raw *y, float *mean, float *invstd, double *scratch, hipStream_t s);
 hipError_t launch_bn_train_backward(const bf16_raw *x, const bf16_raw *y, const bf16_raw *dy, int cs, size_t P, int C, const float *mean,
-                                    const float *invstd, const float *gamma, int relu, bf16_raw *dx, bf16_raw *dres, float *dgamma,
-                                    float *dbeta, double *scratch, hipStream_t s);
+                                    const float *invstd, const float *gamma, const float *beta, int relu, bf16_raw *dx, bf16_raw *dres,
+                                    float *dgamma, float *dbeta, double *scratch, hipStream_t s);  // y == nullptr: no residual, mask from x
 hipError_t launch_bn_train_stats(const bf16_raw *x, int cs, size_t P, int C, double *sums, double *scratch, hipStream_t s);
 hipError_t launch_bn_train_normalize(const bf16_raw *x, int cs, size_t P, int C, const double *sums, double count, const float *gamma,
                                      const float *beta, float eps, const bf16_raw *res, int relu, bf16_raw *y, float *mean, float *invstd,

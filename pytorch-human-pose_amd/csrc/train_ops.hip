@@ -137,6 +137,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restri
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
 }
+// gamma * (x - mean) * invstd + beta: ONE function for the forward and for the backward passes that recompute the ReLU mask from x
+// (HASY = false below), so that both evaluate the same instruction sequence
+__device__ __forceinline__ float bn_affine(float x, float mean, float invstd, float gamma, float beta)
+{
+    return (x - mean) * invstd * gamma + beta;
+}
 // y = act(gamma * (x - mean) * invstd + beta (+ res))
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_raw *__restrict__ x, int cs, size_t P, int C, const float *__restrict__ mean,
                                                        const float *__restrict__ invstd, const float *__restrict__ gamma,
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_raw *__restric
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int c = g * 8 + 2 * k + h;
-                float t = (f[h] - mean[c]) * invstd[c] * gamma[c] + beta[c] + r[h];
+                float t = bn_affine(f[h], mean[c], invstd[c], gamma[c], beta[c]) + r[h];
                 f[h] = relu ? fmaxf(t, 0.f) : t;
             }
             o[k] = (unsigned)f2bf_dev(f[0]) | ((unsigned)f2bf_dev(f[1]) << 16);
@@ -184,17 +190,24 @@ hipError_t launch_bn_train_forward(const bf16_raw *x, int cs, size_t P, int C, c
 // Backward of y = act(gamma * xhat + beta (+ res)), xhat = (x - mean) * invstd:
 //   g = dy * (y > 0 if relu);  dbeta = sum g;  dgamma = sum g * xhat;
 //   dx = gamma * invstd * (g - dbeta / P - xhat * dgamma / P);  dres = g (returned in place of dy when res was used)
+// HASY = false (a BatchNorm without a residual input): y is not read -- without ReLU nothing needs it, with ReLU the mask y > 0 is
+// recomputed from x (bn_affine(x) > 0: what the forward rounded to bf16 and clamped), one tensor pass less in both kernels
+template <bool HASY>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const bf16_raw *__restrict__ x, const bf16_raw *__restrict__ y,
                                                              const bf16_raw *__restrict__ dy, int cs, size_t P, int C,
-                                                             const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
+                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
                                                              double *__restrict__ partial)
 {
     const int C8 = C / 8, g = threadIdx.x % C8, pl = threadIdx.x / C8, npl = 256 / C8;
     double s[8] = {}, q[8] = {};
     if (pl < npl) {
-        float mu[8], is[8];
+        float mu[8], is[8], ga[8], be[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { mu[i] = mean[g * 8 + i]; is[i] = invstd[g * 8 + i]; }
+        for (int i = 0; i < 8; ++i) {
+            mu[i] = mean[g * 8 + i]; is[i] = invstd[g * 8 + i];
+            ga[i] = HASY ? 0.f : gamma[g * 8 + i]; be[i] = HASY ? 0.f : beta[g * 8 + i];
+        }
         auto add = [&](const uint4 &xv, const uint4 &yv, const uint4 &dv) {
             const unsigned xu[4] = {xv.x, xv.y, xv.z, xv.w}, yu[4] = {yv.x, yv.y, yv.z, yv.w}, du[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
@@ -202,7 +215,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const bf16_raw *__r
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float xf = __builtin_bit_cast(float, h ? (xu[k] & 0xffff0000u) : (xu[k] << 16));
-                    const float yf = __builtin_bit_cast(float, h ? (yu[k] & 0xffff0000u) : (yu[k] << 16));
+                    const float yf = HASY ? __builtin_bit_cast(float, h ? (yu[k] & 0xffff0000u) : (yu[k] << 16))
+                                          : bn_affine(xf, mu[2 * k + h], is[2 * k + h], ga[2 * k + h], be[2 * k + h]);
                     float gf = __builtin_bit_cast(float, h ? (du[k] & 0xffff0000u) : (du[k] << 16));
                     if (relu && !(yf > 0.f)) gf = 0.f;
                     s[2 * k + h] += gf;
@@ -217,14 +231,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const bf16_raw *__r
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 xv[u] = *reinterpret_cast<const uint4 *>(x + (p + u * step) * cs + g * 8);
-                yv[u] = *reinterpret_cast<const uint4 *>(y + (p + u * step) * cs + g * 8);
+                yv[u] = HASY ? *reinterpret_cast<const uint4 *>(y + (p + u * step) * cs + g * 8) : make_uint4(0, 0, 0, 0);
                 dv[u] = *reinterpret_cast<const uint4 *>(dy + (p + u * step) * cs + g * 8);
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) add(xv[u], yv[u], dv[u]);
         }
         for (; p < P; p += step)
-            add(*reinterpret_cast<const uint4 *>(x + p * cs + g * 8), *reinterpret_cast<const uint4 *>(y + p * cs + g * 8),
+            add(*reinterpret_cast<const uint4 *>(x + p * cs + g * 8),
+                HASY ? *reinterpret_cast<const uint4 *>(y + p * cs + g * 8) : make_uint4(0, 0, 0, 0),
                 *reinterpret_cast<const uint4 *>(dy + p * cs + g * 8));
     }
     __shared__ double sh[2][256][8 + 1];
@@ -250,10 +265,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double *__re
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
 }
+template <bool HASY>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_raw *__restrict__ x, const bf16_raw *__restrict__ y,
                                                            const bf16_raw *__restrict__ dy, int cs, size_t P, int C,
                                                            const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                           const float *__restrict__ gamma, const float *__restrict__ dgamma,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           const float *__restrict__ dgamma,
                                                            const float *__restrict__ dbeta, int relu, float invP,
                                                            bf16_raw *__restrict__ dx, bf16_raw *__restrict__ dres)
 {
@@ -263,22 +280,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_raw *__res
         const size_t p = i / C8;
         const int g = (int)(i % C8);
         const uint4 xv = *reinterpret_cast<const uint4 *>(x + p * cs + g * 8);
-        const uint4 yv = *reinterpret_cast<const uint4 *>(y + p * cs + g * 8);
+        const uint4 yv = HASY ? *reinterpret_cast<const uint4 *>(y + p * cs + g * 8) : make_uint4(0, 0, 0, 0);
         const uint4 dv = *reinterpret_cast<const uint4 *>(dy + p * cs + g * 8);
         const unsigned xu[4] = {xv.x, xv.y, xv.z, xv.w}, yu[4] = {yv.x, yv.y, yv.z, yv.w}, du[4] = {dv.x, dv.y, dv.z, dv.w};
+        // the eight channels' parameters as 16-byte loads, unconditionally (behind a condition they come one float at a time)
+        float mu[8], is[8], ga[8], be[8], dg[8], db[8];
+        auto ld8 = [&](const float *src, float *dst) {
+            const float4 a = *reinterpret_cast<const float4 *>(src + g * 8), b = *reinterpret_cast<const float4 *>(src + g * 8 + 4);
+            dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+        };
+        ld8(mean, mu); ld8(invstd, is); ld8(gamma, ga); ld8(dgamma, dg); ld8(dbeta, db);
+        if constexpr (!HASY) ld8(beta, be);
         unsigned o[4], r[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float out[2], gr[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int c = g * 8 + 2 * k + h;
+                const int c = 2 * k + h;
                 const float xf = __builtin_bit_cast(float, h ? (xu[k] & 0xffff0000u) : (xu[k] << 16));
-                const float yf = __builtin_bit_cast(float, h ? (yu[k] & 0xffff0000u) : (yu[k] << 16));
+                const float yf = HASY ? __builtin_bit_cast(float, h ? (yu[k] & 0xffff0000u) : (yu[k] << 16))
+                                      : bn_affine(xf, mu[c], is[c], ga[c], be[c]);
                 float gf = __builtin_bit_cast(float, h ? (du[k] & 0xffff0000u) : (du[k] << 16));
                 if (relu && !(yf > 0.f)) gf = 0.f;
-                const float xh = (xf - mean[c]) * invstd[c];
-                out[h] = gamma[c] * invstd[c] * (gf - dbeta[c] * invP - xh * dgamma[c] * invP);
+                const float xh = (xf - mu[c]) * is[c];
+                out[h] = ga[c] * is[c] * (gf - db[c] * invP - xh * dg[c] * invP);
                 gr[h] = gf;
             }
             o[k] = (unsigned)f2bf_dev(out[0]) | ((unsigned)f2bf_dev(out[1]) << 16);
@@ -289,16 +315,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_raw *__res
     }
 }
 
+// y == nullptr: a BatchNorm without a residual input (dres must be nullptr, beta is then needed for the mask); otherwise beta is unused
 hipError_t launch_bn_train_backward(const bf16_raw *x, const bf16_raw *y, const bf16_raw *dy, int cs, size_t P, int C, const float *mean,
-                                    const float *invstd, const float *gamma, int relu, bf16_raw *dx, bf16_raw *dres, float *dgamma,
-                                    float *dbeta, double *scratch, hipStream_t s)
+                                    const float *invstd, const float *gamma, const float *beta, int relu, bf16_raw *dx, bf16_raw *dres,
+                                    float *dgamma, float *dbeta, double *scratch, hipStream_t s)
 {
     const int nblocks = HH_BN_BLOCKS;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblocks), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, relu, scratch);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, scratch, nblocks, C, dgamma, dbeta);
     unsigned grid = (unsigned)((P * (C / 8) + 255) / 256);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, dgamma, dbeta, relu, (float)(1.0 / (double)P), dx, dres);
+    const float invP = (float)(1.0 / (double)P);
+    if (y) {
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(nblocks), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, beta, relu, scratch);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, scratch, nblocks, C, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, beta, dgamma, dbeta, relu, invP, dx, dres);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nblocks), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, beta, relu, scratch);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, scratch, nblocks, C, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, beta, dgamma, dbeta, relu, invP, dx, dres);
+    }
     return hipGetLastError();
 }
 
@@ -354,7 +388,7 @@ hipError_t launch_bn_train_backward_stats(const bf16_raw *x, const bf16_raw *y, 
                                           const float *invstd, int relu, double *sums, float *dgamma, float *dbeta, double *scratch,
                                           hipStream_t s)
 {
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(HH_BN_BLOCKS), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, relu, scratch);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(HH_BN_BLOCKS), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, (const float *)nullptr, (const float *)nullptr, relu, scratch);
     // this rank's sums are also its dbeta / dgamma (the parameter gradients are averaged by DDP like every other one)
     hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, s, scratch, HH_BN_BLOCKS, C, sums, dbeta, dgamma);
     return hipGetLastError();
@@ -367,6 +401,6 @@ hipError_t launch_bn_train_backward_apply(const bf16_raw *x, const bf16_raw *y, 
     hipLaunchKernelGGL(bn_sums_to_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, ga, gb);
     unsigned grid = (unsigned)((P * (C / 8) + 255) / 256);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, gb, ga, relu, (float)(1.0 / count), dx, dres);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0, s, x, y, dy, cs, P, C, mean, invstd, gamma, (const float *)nullptr, gb, ga, relu, (float)(1.0 / count), dx, dres);
     return hipGetLastError();
 }

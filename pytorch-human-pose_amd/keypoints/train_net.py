@@ -59,7 +59,10 @@ class _BNFn(torch.autograd.Function):
         else:
             y, mean, invstd = ops.bn_train_forward(x, gamma, beta, eps, res, relu)
             ctx.count = x.shape[0] * x.shape[2] * x.shape[3]
-        ctx.save_for_backward(x, y, mean, invstd, gamma)
+        # without a residual input the backward needs nothing of y: the ReLU mask is recomputed from x (hh_bn_train_backward_plain);
+        # beta is saved instead (HH_TRAIN_BN_KEEP_Y=1: the stored-output form, for A/B)
+        ctx.plain = res is None and ctx.sync is None and not _KEEP_Y
+        ctx.save_for_backward(x, beta.detach() if ctx.plain else y, mean, invstd, gamma)
         ctx.relu, ctx.has_res = relu, res is not None
         stats.append((mean, invstd, ctx.count))
         return y
@@ -73,8 +76,12 @@ class _BNFn(torch.autograd.Function):
             if ctx.box is not None:
                 ctx.box.g, dres = dres, None
             return dx, dgamma, dbeta, dres, None, None, None, None
-        dx, dgamma, dbeta, dres = ops.bn_train_backward(x, y, dy.contiguous(memory_format=torch.channels_last), mean, invstd, gamma,
-                                                        ctx.relu, want_dres=ctx.has_res)
+        if ctx.plain:  # (y holds beta)
+            dx, dgamma, dbeta, dres = ops.bn_train_backward(x, None, dy.contiguous(memory_format=torch.channels_last), mean, invstd, gamma,
+                                                            ctx.relu, beta=y)
+        else:
+            dx, dgamma, dbeta, dres = ops.bn_train_backward(x, y, dy.contiguous(memory_format=torch.channels_last), mean, invstd, gamma,
+                                                            ctx.relu, want_dres=ctx.has_res)
         if ctx.box is not None:
             ctx.box.g, dres = dres, None
         return dx, dgamma, dbeta, dres, None, None, None, None
@@ -230,6 +237,7 @@ def deconv_k4s2(x: Tensor, m: nn.ConvTranspose2d) -> Tensor:
 
 # ------------------------------------------------------------------------------------------ the net
 _NO_RESBOX = bool(os.environ.get("HH_TRAIN_NO_RESBOX"))  # A/B: the skip gradients through autograd's own accumulation
+_KEEP_Y = bool(os.environ.get("HH_TRAIN_BN_KEEP_Y"))  # A/B: every BatchNorm backward reads its stored output
 
 
 def _boxable(x, c: nn.Conv2d) -> bool:

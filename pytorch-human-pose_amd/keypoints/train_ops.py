@@ -86,10 +86,25 @@ def bn_train_forward(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, 
     return y, mean, invstd
 
 
-def bn_train_backward(x: Tensor, y: Tensor, dy: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, relu: bool = False,
-                      want_dres: bool = False):
-    """-> (dx, dgamma, dbeta, dres or None)"""
+def bn_train_backward(x: Tensor, y, dy: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, relu: bool = False,
+                      want_dres: bool = False, beta=None):
+    """-> (dx, dgamma, dbeta, dres or None).  y = None (with beta): a BatchNorm without a residual input, the ReLU mask is
+    recomputed from x (hh_bn_train_backward_plain)."""
     lib = _lib.load()
+    if y is None:
+        assert beta is not None and not want_dres
+        x, dy = _nhwc(x), _nhwc(dy)
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(256 * C * 2, device=x.device, dtype=torch.float64)
+        g, b = gamma.float().contiguous(), beta.float().contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.hh_bn_train_backward_plain(x.data_ptr(), dy.data_ptr(), B * H * W, C, mean.data_ptr(), invstd.data_ptr(), g.data_ptr(),
+                                                      b.data_ptr(), int(relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                      scratch.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream))
+        return dx, dgamma, dbeta, None
     x, y, dy = _nhwc(x), _nhwc(y), _nhwc(dy)
     B, C, H, W = x.shape
     dx = torch.empty_like(x)

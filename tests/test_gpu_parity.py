@@ -932,6 +932,10 @@ def test_training_building_blocks_conv_and_batchnorm(pkg):
         close(dbeta, beta.grad, ("bn dbeta", C), 2e-2)
         if with_res:
             close(dres, res.grad, ("bn dres", C), 2e-2)
+        else:  # without a residual the backward can do without y (mask recomputed from x by the forward's own function): the same bits
+            px, pg, pb, _ = ops.bn_train_backward(x.detach().to(DEV, torch.bfloat16), None, dy.to(DEV, torch.bfloat16), mean, invstd,
+                                                  gamma.detach().to(DEV), relu, beta=beta.detach().to(DEV))
+            assert torch.equal(px, dx) and torch.equal(pg, dgamma) and torch.equal(pb, dbeta), ("bn backward without y", C, relu)
 
 
 def test_fusion_sum_training_op_matches_torch(pkg):

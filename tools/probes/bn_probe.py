@@ -29,11 +29,14 @@ for B, C, H, W in shapes:
             y, mean, invstd = ops.bn_train_forward(x, gamma, beta, 1e-5, r, True)
         e1.record()
         for _ in range(reps):
-            ops.bn_train_backward(x, y, dy, mean, invstd, gamma, True, want_dres=with_res)
+            if with_res or os.environ.get("BN_PROBE_KEEP_Y"):
+                ops.bn_train_backward(x, y, dy, mean, invstd, gamma, True, want_dres=with_res)
+            else:  # the form the training step uses without a residual: y is not read
+                ops.bn_train_backward(x, None, dy, mean, invstd, gamma, True, beta=beta)
         e2.record()
         torch.cuda.synchronize()
         tf, tb = e0.elapsed_time(e1) / reps * 1e3, e1.elapsed_time(e2) / reps * 1e3
         fb = nbytes * (3 + with_res)            # stats read + normalise read (+ residual) + write
-        bb = nbytes * (7 + with_res)            # (x, y, dy) twice + dx (+ dres)
+        bb = nbytes * ((7 + with_res) if with_res or os.environ.get("BN_PROBE_KEEP_Y") else 5)  # (x, y, dy) twice + dx (+ dres); plain: (x, dy) twice + dx
         out.append(f"{'res' if with_res else 'plain'}: fwd {tf:7.1f} us {fb / tf / 1e6:6.2f} TB/s | bwd {tb:7.1f} us {bb / tb / 1e6:6.2f} TB/s")
     print(f"B{B} C{C:<3d} {H}x{W} ({nbytes / 1e6:6.1f} MB)  " + "  ||  ".join(out), flush=True)
