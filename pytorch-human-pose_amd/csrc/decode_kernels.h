@@ -12,12 +12,16 @@
 #define HH_NMS_TILE 60  // + the 2-pixel halo of the 5x5 maximum = 64 = one wave of columns
 
 // Where the full-resolution maps come from.
-//  mode 0: computed on the fly -- heat = bilinear x2 of `avg` (the stage-averaged 1/2-res map),
-//          tags = bilinear x4 of the 1/4-res tag maps; nothing full-res is ever stored in HBM.
+//  mode 0: computed on the fly -- heat = bilinear x2 of the stage average of the two heatmap outputs, tags = bilinear x4 of the
+//          1/4-res tag maps; nothing full-res is ever stored in HBM.  The stage average itself (1/2-res) is materialised in
+//          `avg` only on the exhaustive path (hh_decoder_set_exact_topk); on the default path `avg` is null and every reader
+//          forms the average values it needs from hm_q / hm_h (round 4: the map was written once and read back three times).
 //  mode 1: explicit full-res arrays (the MPPEHeatmapParser.parse boundary).
 struct DecodeSrc {
     int mode;
-    const float *avg;                  // [B,K,H/2,W/2]
+    const float *avg;                  // [B,K,H/2,W/2] or null
+    const float *hm_q, *hm_h;          // mode 0: the net's heatmap outputs [B,K,H/4,W/4] / [B,K,H/2,W/2], batch strides hm_*_bs
+    int64_t hm_q_bs, hm_h_bs;
     const float *tags_q[HH_MAX_EMB];   // each [B,K,H/4,W/4], batch stride tags_bs[e]
     int64_t tags_bs[HH_MAX_EMB];
     const float *hm_full;              // [B,K,H,W]
@@ -34,9 +38,16 @@ hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float 
 // skip_thr: tiles whose values cannot exceed it emit no candidates (-INFINITY: every tile is processed, the exact top-k)
 hipError_t launch_nms_tile_topk(const DecodeSrc &src, int M, unsigned long long *cand_key, float *cand_val, float *cellmax,
                                 float skip_thr, hipStream_t s);
+// the default front end of hh_decode (mode 0, src.avg == null, det_thr >= 0): stage average + x2 resize + 5x5 NMS + candidates above
+// `thr` in one pass over src.hm_q / src.hm_h (decode_peaks.hip).  cand_key [B*K][peaks_regions(H, W)][M] (0 = empty slot), cellmax =
+// the bf16 cell bounds of the refine scans
+int peaks_regions(int H, int W);
+// ctr: 8 work counters of the persistent grid, zero at launch (launch_adjust_scores clears them again behind it)
+hipError_t launch_peaks(const DecodeSrc &src, int M, unsigned long long *cand_key, float *cellmax, float thr, int *ctr, hipStream_t s);
 // images flagged HH_DECODE_FALLBACK: joints[b, 0, k] = the top-1 candidate of joint k recomputed from the map
 hipError_t launch_fallback_top1(const DecodeSrc &src, int M, const int32_t *flags, float *joints, hipStream_t s);
-// per (b,k): merge the tiles' candidates -> scores_k, coords_k (x,y), tags_k
+// per (b,k): merge the tiles' candidates -> scores_k, coords_k (x,y), tags_k (cand_val null: keys of positive values only, the score is
+// read out of the key)
 hipError_t launch_topk_merge(const DecodeSrc &src, int M, int ntiles, unsigned long long *cand_key, const float *cand_val,
                              float *tags_k, int32_t *coords_k, float *scores_k, hipStream_t s);
 // per image: match_by_tag (+ the "no group" fallback); joints [B,M,K,3+E], num_people [B].  bounds_src != nullptr (mode 0, refine):
@@ -50,7 +61,7 @@ hipError_t launch_munkres_debug(const double *cost, int n, int32_t *out, hipStre
 // per image: quarter-pixel adjust (optional) and person scores
 // adjust + person scores + (refine != 0) the mean tag of every person and the lists of its missing joints
 hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, int refine, float *joints, const int32_t *num_people, float *scores,
-                                float *ws_prev, int32_t *ws_jobs, hipStream_t s);
+                                float *ws_prev, int32_t *ws_jobs, int *peaks_ctr, hipStream_t s);
 // refine: the full-map argmax for every missing joint (work lists from launch_adjust_scores, tag bounds from launch_match), applied
 // to `joints` by the scanning workgroup
 hipError_t launch_refine(const DecodeSrc &src, int M, float *joints, const float *ws_prev, const int32_t *ws_jobs, const float *cellmax,

@@ -2,51 +2,9 @@
 // every fused multiply-add below is explicit because the results must be bit-identical to
 // the reference's torch-CPU / numpy arithmetic (see oracle/decode_oracle.c for the
 // experimentally pinned formulas).
-#include "decode_kernels.h"
-
-#include <math.h>
+#include "decode_dev.h"
 
 #include <utility>
-
-typedef unsigned long long u64;
-
-// ------------------------------------------------------------------ bilinear sampling
-// F.interpolate(mode="bilinear", align_corners=False), torch CPU fp32 (results.py:48-67)
-struct Lin { int i0, i1; float w0, w1; };
-
-__device__ __forceinline__ Lin src_index(int in_size, float scale, int dst)
-{
-    float r = __builtin_fmaf(scale, (float)dst + 0.5f, -0.5f);
-    if (r < 0.f) r = 0.f;
-    const int a = (int)r;
-    float l1 = r - (float)a;
-    l1 = fminf(fmaxf(l1, 0.f), 1.f);
-    Lin o;
-    o.i0 = a; o.i1 = a + (a < in_size - 1 ? 1 : 0); o.w1 = l1; o.w0 = 1.f - l1;
-    return o;
-}
-
-__device__ __forceinline__ float bilerp(const float *__restrict__ img, int w, const Lin &ly, const Lin &lx)
-{
-    const float *r0 = img + (size_t)ly.i0 * w, *r1 = img + (size_t)ly.i1 * w;
-    const float a = __builtin_fmaf(r0[lx.i0], lx.w0, r0[lx.i1] * lx.w1);
-    const float b = __builtin_fmaf(r1[lx.i0], lx.w0, r1[lx.i1] * lx.w1);
-    return __builtin_fmaf(a, ly.w0, b * ly.w1);
-}
-
-// full-resolution heat value / tag value at (b,k,y,x)
-__device__ __forceinline__ float heat_at(const DecodeSrc &s, int b, int k, int y, int x)
-{
-    if (s.mode == 1) return s.hm_full[(((size_t)b * s.K + k) * s.H + y) * s.W + x];
-    const int hh = s.H >> 1, wh = s.W >> 1;
-    return bilerp(s.avg + ((size_t)b * s.K + k) * hh * wh, wh, src_index(hh, s.scale_h2, y), src_index(wh, s.scale_w2, x));
-}
-__device__ __forceinline__ float tag_at(const DecodeSrc &s, int b, int k, int y, int x, int e)
-{
-    if (s.mode == 1) return s.tags_full[((((size_t)b * s.K + k) * s.H + y) * s.W + x) * s.E + e];
-    const int hq = s.H >> 2, wq = s.W >> 2;
-    return bilerp(s.tags_q[e] + (size_t)b * s.tags_bs[e] + (size_t)k * hq * wq, wq, src_index(hq, s.scale_h4, y), src_index(wq, s.scale_w4, x));
-}
 
 // ------------------------------------------------------------------ stage average
 // results.py:225-226: match_heatmaps_size (1/4 -> 1/2) then torch.stack(...).mean(dim=0)
@@ -75,52 +33,11 @@ hipError_t launch_stage_average(const float *hm_q, int64_t hm_q_bs, const float 
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------ sortable keys
-// Larger key = larger value; between equal values the smaller flat index wins (torch.topk
-// leaves that order unspecified; the oracle uses the same rule). -0 == +0; NaN ranks lowest.
-__device__ __forceinline__ u64 make_key(float v, unsigned idx)
-{
-    if (v != v) return 1ull + (u64)(0xffffffffu - idx);
-    if (v == 0.f) v = 0.f;
-    unsigned bits = __float_as_uint(v);
-    bits = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-    return ((u64)bits << 32) | (u64)(0xffffffffu - idx);
-}
-__device__ __forceinline__ u64 wave_max_u64(u64 v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const u64 o = __shfl_xor(v, off);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
-// bf16 roundings toward -inf / +inf (finite inputs): truncation moves toward zero, so step away from zero when bits were lost
-__device__ __forceinline__ unsigned short bf16_floor(float f)
-{
-    const unsigned u = __float_as_uint(f);
-    unsigned short t = (unsigned short)(u >> 16);
-    if ((u & 0xffffu) && (u >> 31)) ++t;  // negative and inexact: one step more negative
-    return t;
-}
-__device__ __forceinline__ unsigned short bf16_ceil(float f)
-{
-    const unsigned u = __float_as_uint(f);
-    unsigned short t = (unsigned short)(u >> 16);
-    if ((u & 0xffffu) && !(u >> 31)) ++t;  // positive and inexact: one step more positive
-    return t;
-}
-
 // ------------------------------------------------------------------ NMS + per-tile top-M
 // grouping.py:80-83 (5x5 max-pool NMS: hm * (pool(hm) == hm)) and the first half of
 // top_k (grouping.py:147-153).  One workgroup = one 64x64 full-resolution tile of one (b,k)
 // map, computed from L2-resident low-res data; separable 5x5 max through LDS; then M rounds
 // of workgroup-wide arg-max (wave shuffles + one LDS exchange per round).
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it parks the wave until every
-// global store it has issued (cell maxima, candidate lists) is acknowledged by memory: a full round trip per barrier that no
-// thread of the workgroup depends on.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef HH_NMS_DEBUG  // phase stamps of a sample of workgroups, read by tools/probes/nms_probe.hip only
 __device__ long long g_nms_dbg[4096 * 8];
 #define NMS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x >= 8192 && blockIdx.x < 8192 + 4096) g_nms_dbg[(blockIdx.x - 8192) * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -573,7 +490,8 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const DecodeSrc src, in
         int x = 0, y = 0;
         if (gp >= 0) {
             const unsigned idx = 0xffffffffu - (unsigned)(g & 0xffffffffull);
-            sc = vals[gp];
+            // (the peaks pass writes keys only: a positive value's key holds its bits)
+            sc = cand_val ? vals[gp] : __uint_as_float((unsigned)(g >> 32) & 0x7fffffffu);
             x = (int)(idx % (unsigned)src.W);
             y = (int)(idx / (unsigned)src.W);
         }
@@ -1129,13 +1047,14 @@ hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const floa
 // grouping.py:172-191 and :276 (scores = joints[..., 2].mean(1), taken BEFORE refine)
 __global__ __launch_bounds__(256) void adjust_scores_kernel(const DecodeSrc src, int M, int adjust, int refine, float *__restrict__ joints,
                                                             const int32_t *__restrict__ num_people, float *__restrict__ scores,
-                                                            float *__restrict__ ws_prev, int32_t *__restrict__ ws_jobs)
+                                                            float *__restrict__ ws_prev, int32_t *__restrict__ ws_jobs, int *__restrict__ peaks_ctr)
 {
     // + the first step of refine (grouping.py:200-214: the mean tag of a person's detected joints, read at the adjusted
     // coordinates' pixel) and the work lists of the arg-max pass: the tag of every (person, joint) is sampled by the thread that
     // adjusts it -- P * K independent reads instead of one thread per person walking its joints one dependent read after the other
     __shared__ float tl[HH_MAX_PEOPLE * 64 * HH_MAX_EMB];  // [p][k][e]; K <= 64
     const int b = blockIdx.x, tid = threadIdx.x, K = src.K, E = src.E, D = 3 + E;
+    if (b == 0 && tid < 8 && peaks_ctr) peaks_ctr[tid] = 0;  // the work counters of peaks_region_kernel, for the next decode call
     const int P = min(num_people[b], M);
     float *J = joints + (size_t)b * M * K * D;
     for (int i = tid; i < P * K; i += 256) {
@@ -1187,9 +1106,9 @@ __global__ __launch_bounds__(256) void adjust_scores_kernel(const DecodeSrc src,
 }
 
 hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, int refine, float *joints, const int32_t *num_people, float *scores,
-                                float *ws_prev, int32_t *ws_jobs, hipStream_t s)
+                                float *ws_prev, int32_t *ws_jobs, int *peaks_ctr, hipStream_t s)
 {
-    hipLaunchKernelGGL(adjust_scores_kernel, dim3(src.B), dim3(256), 0, s, src, M, adjust, refine, joints, num_people, scores, ws_prev, ws_jobs);
+    hipLaunchKernelGGL(adjust_scores_kernel, dim3(src.B), dim3(256), 0, s, src, M, adjust, refine, joints, num_people, scores, ws_prev, ws_jobs, peaks_ctr);
     return hipGetLastError();
 }
 
@@ -1235,7 +1154,7 @@ __global__ __launch_bounds__(256, 4) void refine_argmax_kernel(const DecodeSrc s
                 for (int y = 0; y < src.H; ++y) pixel(y, x);
         } else {
             const int hq = src.H >> 2, wq = src.W >> 2, wh = src.W >> 1;
-            const float *avg = src.avg + ((size_t)b * src.K + k) * (size_t)(src.H >> 1) * wh;
+            const float *avg = src.avg ? src.avg + ((size_t)b * src.K + k) * (size_t)(src.H >> 1) * wh : nullptr;
             const unsigned short *cmaxu = reinterpret_cast<const unsigned short *>(cellmax) + ((size_t)b * src.K + k) * hq * wq;
             auto cmax_at = [&](int c) { return __uint_as_float((unsigned)cmaxu[c] << 16); };  // bf16 upper bound of the cell maximum
             constexpr int TO[4] = {0, 0, 1, 1};  // tag source row offset (from q-1) of sub-pixel j, x4 upsampling
@@ -1252,14 +1171,45 @@ __global__ __launch_bounds__(256, 4) void refine_argmax_kernel(const DecodeSrc s
                     return;
                 }
                 float hrow[4][4];
-                const float *a0 = avg + (size_t)(2 * qy - 1) * wh + 2 * qx - 1;
+                float a4[4][4];  // the stage average at half-res rows 2qy-1 .. 2qy+2, columns 2qx-1 .. 2qx+2
+                if (src.avg) {
+                    const float *a0 = avg + (size_t)(2 * qy - 1) * wh + 2 * qx - 1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float t[4] = {a0[r * wh], a0[r * wh + 1], a0[r * wh + 2], a0[r * wh + 3]};
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) a4[r][cc] = a0[r * wh + cc];
+                } else {
+                    // not materialised (default path): formed from the 3x3 quarter-res and 4x4 half-res samples under the cell, all
+                    // loaded before the first use; interior cells, so the x2 source patterns are the fixed ones of avg_at()
+                    const float *q0 = src.hm_q + (size_t)b * src.hm_q_bs + ((size_t)k * hq + qy - 1) * wq + qx - 1;
+                    const float *h0 = src.hm_h + (size_t)b * src.hm_h_bs + ((size_t)k * (src.H >> 1) + 2 * qy - 1) * wh + 2 * qx - 1;
+                    float t9[3][3], h16[4][4];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) t9[r][cc] = q0[r * wq + cc];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) h16[r][cc] = h0[r * wh + cc];
+                    constexpr int QO[4] = {0, 0, 1, 1};  // lower quarter-res sample (from q-1) of half-res sample 2q-1+j
+                    constexpr float QW0[4] = {0.75f, 0.25f, 0.75f, 0.25f}, QW1[4] = {0.25f, 0.75f, 0.25f, 0.75f};
+                    float uph[3][4];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) uph[r][cc] = __builtin_fmaf(t9[r][QO[cc]], QW0[cc], t9[r][QO[cc] + 1] * QW1[cc]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc)
+                            a4[r][cc] = (__builtin_fmaf(uph[QO[r]][cc], QW0[r], uph[QO[r] + 1][cc] * QW1[r]) + h16[r][cc]) / 2.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int jx = 0; jx < 4; ++jx)
-                        hrow[r][jx] = __builtin_fmaf(t[HO[jx]], 1.f - HW1[jx], t[HO[jx] + 1] * HW1[jx]);
-                }
+                        hrow[r][jx] = __builtin_fmaf(a4[r][HO[jx]], 1.f - HW1[jx], a4[r][HO[jx] + 1] * HW1[jx]);
                 float dist2[16];
 #pragma unroll
                 for (int e = 0; e < HH_MAX_EMB; ++e) {

@@ -15,6 +15,7 @@ struct hh_decoder {
     float *avg = nullptr, *cellmax = nullptr, *tagb = nullptr, *cand_val = nullptr, *tags_k = nullptr, *scores_k = nullptr, *ws_tags = nullptr, *ws_prev = nullptr;
     unsigned long long *cand_key = nullptr;
     int32_t *coords_k = nullptr, *flags = nullptr, *ws_jobs = nullptr;  // flags [rB]: HH_DECODE_* bits of the last call
+    int *pk_ctr = nullptr;  // work counters of the peaks pass: zero between decode calls
     std::vector<void *> allocs;
     int lastB = 0, lastE = 0;
     int exact_topk = 0;   // 1: every tile is processed, so hh_decoder_read_topk returns the reference's full top_k
@@ -59,6 +60,8 @@ int hh_decoder::reserve(int B, int H, int W, int E)
     if (alloc(((size_t)nB * M * K * 8 + 8) * 4, (void **)&ws_jobs)) return 1;  // 8 counters + 8 job queues (one per XCD)
     if (alloc((size_t)nB * 4, (void **)&flags)) return 1;
     HH_CHECK_HIP(hipMemset(flags, 0, (size_t)nB * 4));
+    if (alloc(64, (void **)&pk_ctr)) return 1;
+    HH_CHECK_HIP(hipMemset(pk_ctr, 0, 64));
     rB = nB; rH = nH; rW = nW; rE = nE;
     return 0;
 }
@@ -68,16 +71,26 @@ int hh_decoder::run(DecodeSrc &src, int adjust, int refine, float *joints, float
     src.K = K;
     src.scale_h2 = (float)(src.H / 2) / (float)src.H; src.scale_w2 = (float)(src.W / 2) / (float)src.W;
     src.scale_h4 = (float)(src.H / 4) / (float)src.H; src.scale_w4 = (float)(src.W / 4) / (float)src.W;
-    const int nt = ntiles_of(src.H, src.W);
-    // Tiles that cannot hold a pixel above det_thr are skipped (only for det_thr >= 0: the empty candidate slots read as score 0,
-    // which must fail `score > det_thr`); mode 1 / other scales always run every tile.
+    // Work that cannot produce a pixel above det_thr is skipped (only for det_thr >= 0: the empty candidate slots read as score 0,
+    // which must fail `score > det_thr`); mode 1 and the exhaustive top-k (hh_decoder_set_exact_topk) process every 60x60 tile.
     const bool skip = !exact_topk && det_thr >= 0.0 && src.mode == 0;
-    // the largest float <= det_thr: `bound <= skip_thr` then implies `(double)score <= det_thr` for every pixel of the tile
+    // the largest float <= det_thr: `bound <= thr_f` then implies `(double)score <= det_thr` for every pixel the bound covers
     float thr_f = (float)det_thr;
     if ((double)thr_f > det_thr) thr_f = nextafterf(thr_f, -INFINITY);
-    HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, cellmax, skip ? thr_f : -INFINITY, s));
+    if (skip) {
+        // default path (round 4): one pass over the net's outputs forms the stage average in LDS, finds the peaks above det_thr and
+        // leaves the cell bounds of the refine scans; the averaged map is not written (src.avg stays null: readers form its values)
+        HH_CHECK_HIP(launch_peaks(src, M, cand_key, cellmax, thr_f, pk_ctr, s));
+        HH_CHECK_HIP(launch_topk_merge(src, M, peaks_regions(src.H, src.W), cand_key, nullptr, tags_k, coords_k, scores_k, s));
+    } else {
+        if (src.mode == 0) {
+            HH_CHECK_HIP(launch_stage_average(src.hm_q, src.hm_q_bs, src.hm_h, src.hm_h_bs, avg, src.B, K, src.H / 4, src.W / 4, s));
+            src.avg = avg;
+        }
+        HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, cellmax, -INFINITY, s));
+        HH_CHECK_HIP(launch_topk_merge(src, M, ntiles_of(src.H, src.W), cand_key, cand_val, tags_k, coords_k, scores_k, s));
+    }
     last_exact = !skip;
-    HH_CHECK_HIP(launch_topk_merge(src, M, nt, cand_key, cand_val, tags_k, coords_k, scores_k, s));
     // (mode 0: the tag bounds of the refine scans and the cleared queue counters ride in the matching launch)
     const bool bounds = refine && src.mode == 0;
     if (refine && !bounds) HH_CHECK_HIP(hipMemsetAsync(ws_jobs, 0, 32, s));  // the 8 queue counters
@@ -85,7 +98,7 @@ int hh_decoder::run(DecodeSrc &src, int adjust, int refine, float *joints, float
                               bounds ? &src : nullptr, tagb, ws_jobs, s));
     flags_last = flags_out ? flags_out : flags;
     if (skip) HH_CHECK_HIP(launch_fallback_top1(src, M, flags_last, joints, s));
-    HH_CHECK_HIP(launch_adjust_scores(src, M, adjust, refine, joints, num_people, scores, ws_prev, ws_jobs, s));
+    HH_CHECK_HIP(launch_adjust_scores(src, M, adjust, refine, joints, num_people, scores, ws_prev, ws_jobs, pk_ctr, s));
     if (refine) HH_CHECK_HIP(launch_refine(src, M, joints, ws_prev, ws_jobs, cellmax, tagb, s));
     lastB = src.B; lastE = src.E;
     return 0;
@@ -121,9 +134,9 @@ int hh_decode(hh_decoder *dec, const float *hm_q, int64_t hm_q_bstride, const fl
     const int H = 4 * hq, W = 4 * wq;
     if (dec->reserve(B, H, W, E)) return 1;
     hipStream_t s = (hipStream_t)stream;
-    HH_CHECK_HIP(launch_stage_average(hm_q, hm_q_bstride, hm_h, hm_h_bstride, dec->avg, B, dec->K, hq, wq, s));
     DecodeSrc src{};
-    src.mode = 0; src.avg = dec->avg; src.B = B; src.H = H; src.W = W; src.E = E;
+    src.mode = 0; src.avg = nullptr; src.hm_q = hm_q; src.hm_q_bs = hm_q_bstride; src.hm_h = hm_h; src.hm_h_bs = hm_h_bstride;
+    src.B = B; src.H = H; src.W = W; src.E = E;
     for (int e = 0; e < E; ++e) { src.tags_q[e] = tags_q[e]; src.tags_bs[e] = tags_bstride[e]; }
     return dec->run(src, adjust, refine, joints, scores, num_people, flags, s);
 }
