@@ -214,23 +214,50 @@ def train_bench(args, pkg, dist, rank, world, dev):
         dist.destroy_process_group()
 
 
+def _visible_gpus():
+    """GPUs this process would see, counted without a HIP call (torch.cuda.device_count() may go through hipGetDeviceCount on a ROCm
+    build and leave an initialised runtime in the parent): the KFD topology's nodes with SIMDs, cut by HIP_/ROCR_VISIBLE_DEVICES."""
+    n = 0
+    try:
+        root = "/sys/class/kfd/kfd/topology/nodes"
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except OSError:
+        return None if os.path.exists("/dev/kfd") else 0  # a driver without a readable topology: let the ranks find out; no driver: no GPUs
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(n):
-    """`python bench.py --gpus N` without a launcher: run the N-rank job as a child `torch.distributed.run` (rendezvous on
-    127.0.0.1, a free port) with this command line, and exit with its code.  Nothing here touches the GPU (counting devices
-    does not initialise it), so the ranks are the first GPU users."""
+    """`python bench.py --gpus N` without a launcher: run the N-rank job as a CHILD `torch.distributed.run` (rendezvous on 127.0.0.1,
+    a free port) with this command line, and exit with its code.  It must stay a child process and never become an exec: a process
+    that has touched the GPU must not replace itself on this pool.  The parent makes no HIP call at all (the device count comes from
+    sysfs), so the ranks are the first GPU users.  A rendezvous port that was taken between the probe and the launch: try again."""
     import socket
     import subprocess
 
-    if os.environ.get("HH_BENCH_REHEARSAL") != "cpu":
-        have = torch.cuda.device_count()
-        if have < n and not os.environ.get("HH_BENCH_REHEARSAL"):
+    if not os.environ.get("HH_BENCH_REHEARSAL"):
+        have = _visible_gpus()
+        if have is not None and have < n:
             sys.exit(f"bench.py: --gpus {n} but this node shows {have} GPU(s)")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.call(cmd))
+    rc = 1
+    for _attempt in range(3):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(proc.stderr)
+        rc = proc.returncode
+        if rc == 0 or "Address already in use" not in proc.stderr:
+            break
+    sys.exit(rc)
 
 
 def main():

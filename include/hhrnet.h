@@ -167,11 +167,12 @@ int hh_flip_merge(float *hm, int64_t hm_bstride, const float *hm_flipped, int64_
 hh_decoder *hh_decoder_create(int num_kpts, int max_people, double det_thr, double tag_thr);
 void hh_decoder_destroy(hh_decoder *dec);
 int hh_decoder_reserve(hh_decoder *dec, int B, int H, int W, int E); /* H, W = full (model-input) resolution */
-/* By default hh_decode skips the NMS / top-k work of every 60x60 tile whose half-resolution source values cannot exceed
- * det_thr: such a tile cannot contribute a candidate that survives match_by_tag's `score > det_thr` filter
- * (grouping.py:98-102), so joints / scores / num_people are unchanged, bit for bit; the no-group fallback's top-1 candidates
- * are then recomputed from the maps for the flagged images.  What changes is the candidate list itself (sub-threshold
- * entries are missing): enable = 1 processes every tile, which hh_decoder_read_topk (the reference's full top_k) needs.   */
+/* By default hh_decode skips the NMS / top-k work of every 16x16-pixel block whose averaged half-resolution source values cannot
+ * exceed det_thr (and only keeps peaks above it): such pixels cannot contribute a candidate that survives match_by_tag's
+ * `score > det_thr` filter (grouping.py:98-102), so joints / scores / num_people are unchanged, bit for bit; the no-group
+ * fallback's top-1 candidates are then recomputed from the maps for the flagged images.  What changes is the candidate list
+ * itself (sub-threshold entries are missing): enable = 1 takes the exhaustive path (the stage average materialised, every
+ * 60x60 tile processed), which hh_decoder_read_topk (the reference's full top_k) needs.                                    */
 int hh_decoder_set_exact_topk(hh_decoder *dec, int enable);
 
 /* InferenceKeypointsResult.from_preds aggregation + MPPEHeatmapParser.parse, batched:
@@ -294,12 +295,13 @@ int hh_resize_accumulate(const float *src, int64_t src_bstride, int B, int K, in
 
 /* Candidates of the last hh_decode/hh_parse call (MPPEHeatmapParser.top_k, grouping.py:147-170),
  * copied to host: tags_k [B,K,max_people,E], coords_k [B,K,max_people,2] (x,y), scores_k [B,K,max_people].
- * Synchronous; for parity tests.                                                        */
+ * Synchronous; for parity tests.  Needs the exhaustive candidate lists: hh_decoder_set_exact_topk(dec, 1) before the decode. */
+int hh_decoder_read_topk(hh_decoder *dec, float *tags_k, int32_t *coords_k, float *scores_k);
+
 /* Test hook: the matcher's assignment solver (munkres 1.1.4's step machine, grouping.py:55-59, as one wavefront) alone on one
  * square float64 cost matrix in host memory, n <= 32: star[i] = the column assigned to row i.  Pad a rectangular problem with zeros
  * as munkres.pad_matrix does.  */
 int hh_debug_munkres(const double *cost, int n, int32_t *star);
-int hh_decoder_read_topk(hh_decoder *dec, float *tags_k, int32_t *coords_k, float *scores_k);
 
 /* get_affine_transform(center, scale, rot=0, output_size, inverse) of base/transforms/utils.py:25-57 -> the 2x3 matrix
  * (row-major, 6 doubles) cv2.getAffineTransform returns for the reference's three float32 point pairs: the 6x6 system solved

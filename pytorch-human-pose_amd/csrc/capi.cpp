@@ -275,7 +275,11 @@ static int conv2d_impl(const void *x, int B, int H, int W, int cin, const float 
         int dev = 0;
         HH_CHECK_HIP(hipGetDevice(&dev));
         float *&zeros = zeros_dev[dev & 63];
-        if (!zeros) { HH_CHECK_HIP(hipMalloc((void **)&zeros, 4096 * 4)); HH_CHECK_HIP(hipMemset(zeros, 0, 4096 * 4)); }
+        if (!zeros) {  // (once per device; the wait: a null-stream memset is not ordered in front of launches on a non-blocking stream)
+            HH_CHECK_HIP(hipMalloc((void **)&zeros, 4096 * 4));
+            HH_CHECK_HIP(hipMemset(zeros, 0, 4096 * 4));
+            HH_CHECK_HIP(hipDeviceSynchronize());
+        }
         zbias = zeros;
     } else if (bias && co == coutp) {
         zbias = const_cast<float *>(bias);
@@ -367,7 +371,8 @@ int hh_pack_conv_weights_batch(int n, const float *const *w, void *const *packed
 int64_t hh_conv2d_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int ks, int stride)
 {
     const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
-    return (int64_t)(conv_wgrad_num_workers(B, Ho, Wo, stride, cin, cout) + 16) * ks * ks * round_up_i(cout, 64) * round_up_i(cin, 64) * 4;  // + the 16-row stage buffer of the reduction
+    // one partial-sum set [ks*ks][cout64][cin64] per worker; the reduction combines them in LDS (no staging rows since round 3)
+    return (int64_t)conv_wgrad_num_workers(B, Ho, Wo, stride, cin, cout) * ks * ks * round_up_i(cout, 64) * round_up_i(cin, 64) * 4;
 }
 
 int hh_conv2d_wgrad(const void *x, const void *dy, int B, int H, int W, int cin, int cout, int ks, int stride, int pad_y, int pad_x, float *dw,

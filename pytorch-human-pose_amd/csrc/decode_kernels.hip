@@ -408,8 +408,10 @@ hipError_t launch_fallback_top1(const DecodeSrc &src, int M, const int32_t *flag
 // second half of top_k (grouping.py:152-170): global top-M, tag gather, x = idx % w, y = idx / w
 __global__ __launch_bounds__(256) void topk_merge_kernel(const DecodeSrc src, int M, int ntiles, u64 *__restrict__ cand_key,
                                                          const float *__restrict__ cand_val, float *__restrict__ tags_k,
-                                                         int32_t *__restrict__ coords_k, float *__restrict__ scores_k)
+                                                         int32_t *__restrict__ coords_k, float *__restrict__ scores_k, int *__restrict__ peaks_ctr)
 {
+    // the work counters of peaks_region_kernel (the launch in front of this one) go back to zero for the next decode call
+    if (peaks_ctr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < HH_PEAKS_PARTS) peaks_ctr[threadIdx.x] = 0;
     constexpr int NST = 4096;  // candidate keys of a map staged in LDS when they fit (81 tiles x 30 at 512x512)
     __shared__ u64 skeys[NST];
     __shared__ u64 wbest[2][4];
@@ -488,7 +490,8 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const DecodeSrc src, in
         const int gp = win_pos[tid];
         float sc = 0.f;
         int x = 0, y = 0;
-        if (gp >= 0) {
+        // (a key always names a pixel of the map; the test keeps a corrupted list from turning into an out-of-bounds gather)
+        if (gp >= 0 && 0xffffffffu - (unsigned)(g & 0xffffffffull) < (unsigned)(src.H * src.W)) {
             const unsigned idx = 0xffffffffu - (unsigned)(g & 0xffffffffull);
             // (the peaks pass writes keys only: a positive value's key holds its bits)
             sc = cand_val ? vals[gp] : __uint_as_float((unsigned)(g >> 32) & 0x7fffffffu);
@@ -503,10 +506,10 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const DecodeSrc src, in
 }
 
 hipError_t launch_topk_merge(const DecodeSrc &src, int M, int ntiles, u64 *cand_key, const float *cand_val, float *tags_k,
-                             int32_t *coords_k, float *scores_k, hipStream_t s)
+                             int32_t *coords_k, float *scores_k, int *peaks_ctr, hipStream_t s)
 {
     hipLaunchKernelGGL(topk_merge_kernel, dim3(src.K, src.B), dim3(256), 0, s, src, M, ntiles, cand_key, cand_val, tags_k,
-                       coords_k, scores_k);
+                       coords_k, scores_k, peaks_ctr);
     return hipGetLastError();
 }
 
@@ -577,27 +580,36 @@ __device__ __forceinline__ float np_mean18(const float *rows, int n)
 // thread = one quarter-res column x TBR consecutive rows: the 3-wide row minima / maxima are made once per source row and
 // slide down the column (3.75 loads per cell instead of 9; clamped border rows / columns repeat a tap, which min / max ignore)
 constexpr int TBR = 8;
-__device__ __forceinline__ void tag_bounds_part(const DecodeSrc &src, float *__restrict__ tagb, int32_t *__restrict__ ws_jobs, int vb, int lane)
+// Round 4: also the tag hull of every 8x8-cell SUPER (suptag, for refine_bb_kernel): a thread's TBR = 8 rows are one super's rows, and
+// eight neighbouring lanes hold its eight columns (the columns are padded to a multiple of 8 per row block, lanes past the map idle).
+__host__ __device__ __forceinline__ long long tag_bounds_units(int B, int K, int hq, int wq)
+{
+    return (long long)B * K * ((hq + TBR - 1) / TBR) * ((wq + 7) & ~7);
+}
+__device__ __forceinline__ void tag_bounds_part(const DecodeSrc &src, float *__restrict__ tagb, unsigned *__restrict__ suptag, int32_t *__restrict__ ws_jobs,
+                                                int vb, int lane)
 {
     if (vb == 0 && lane < 8) ws_jobs[lane] = 0;
-    const int hq = src.H >> 2, wq = src.W >> 2, E = src.E;
-    const int nrb = (hq + TBR - 1) / TBR, per_map = nrb * wq;
+    const int hq = src.H >> 2, wq = src.W >> 2, E = src.E, wq8 = (wq + 7) & ~7;
+    const int nrb = (hq + TBR - 1) / TBR, per_map = nrb * wq8;
     const long long L = (long long)vb * 64 + lane;
-    if (L >= (long long)src.B * src.K * per_map) return;
+    if (L >= (long long)src.B * src.K * per_map) return;  // (whole groups of 8 lanes: per_map is a multiple of 8)
     const int map = (int)(L / per_map), it = (int)(L % per_map);
     const int k = map % src.K, b = map / src.K;
     {
-        const int qx = it % wq, qy0 = (it / wq) * TBR;
-        const int xa = max(qx - 1, 0), xb = min(qx + 1, wq - 1);
+        const int qx = it % wq8, qy0 = (it / wq8) * TBR;
+        const bool live = qx < wq;
+        const int qc = min(qx, wq - 1), xa = max(qc - 1, 0), xb = min(qc + 1, wq - 1);
         for (int e = 0; e < E; ++e) {
             const float *tq = src.tags_q[e] + (size_t)b * src.tags_bs[e] + (size_t)k * hq * wq;
             float rlo[TBR + 2], rhi[TBR + 2];
 #pragma unroll
             for (int r = 0; r < TBR + 2; ++r) {
                 const float *row = tq + (size_t)min(max(qy0 - 1 + r, 0), hq - 1) * wq;
-                const float t0 = row[xa], t1 = row[qx], t2 = row[xb];
+                const float t0 = row[xa], t1 = row[qc], t2 = row[xb];
                 rlo[r] = fminf(fminf(t0, t1), t2); rhi[r] = fmaxf(fmaxf(t0, t1), t2);
             }
+            float slo = INFINITY, shi = -INFINITY;  // the hull of this thread's cells, as stored
 #pragma unroll
             for (int r = 0; r < TBR; ++r) {
                 if (qy0 + r >= hq) break;
@@ -605,9 +617,16 @@ __device__ __forceinline__ void tag_bounds_part(const DecodeSrc &src, float *__r
                 const float slack = 1e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-30f;  // >> 3 roundings of a convex combination
                 // stored as a bf16 pair in one dword (lo rounded DOWN, hi rounded UP: the bound only gets looser), which
                 // halves what the arg-max scans have to read per cell
-                reinterpret_cast<unsigned *>(tagb)[(((size_t)b * src.K + k) * hq * wq + (size_t)(qy0 + r) * wq + qx) * E + e] =
-                    (unsigned)bf16_floor(lo - slack) | ((unsigned)bf16_ceil(hi + slack) << 16);
+                const unsigned lh = (unsigned)bf16_floor(lo - slack) | ((unsigned)bf16_ceil(hi + slack) << 16);
+                if (live) reinterpret_cast<unsigned *>(tagb)[(((size_t)b * src.K + k) * hq * wq + (size_t)(qy0 + r) * wq + qx) * E + e] = lh;
+                slo = fminf(slo, __uint_as_float(lh << 16)); shi = fmaxf(shi, __uint_as_float(lh & 0xffff0000u));
             }
+            if (!live) { slo = INFINITY; shi = -INFINITY; }
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) { slo = fminf(slo, __shfl_xor(slo, off)); shi = fmaxf(shi, __shfl_xor(shi, off)); }
+            if (suptag && (qx & 7) == 0)  // (bf16 values: the halves are exact)
+                suptag[(((size_t)b * src.K + k) * nrb + qy0 / TBR) * ((wq + 7) >> 3) * E + (size_t)(qx >> 3) * E + e] =
+                    (__float_as_uint(slo) >> 16) | (__float_as_uint(shi) & 0xffff0000u);
         }
     }
 }
@@ -850,12 +869,13 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
                                                    double det_thr,
                                                    double tag_thr, float *__restrict__ joints, int32_t *__restrict__ num_people,
                                                    float *__restrict__ ws_tags, int32_t *__restrict__ flags, int stage, int nimg,
-                                                   const DecodeSrc src, float *__restrict__ tagb, int32_t *__restrict__ ws_jobs)
+                                                   const DecodeSrc src, float *__restrict__ tagb, unsigned *__restrict__ suptag,
+                                                   int32_t *__restrict__ ws_jobs)
 {
     __shared__ MatchShared S;
     extern __shared__ float staged[];  // the image's candidates and group tag lists, when they fit (stage != 0)
     if ((int)blockIdx.x >= nimg) {  // the workgroups behind the images': tag bounds for the refine scans (tag_bounds_part)
-        tag_bounds_part(src, tagb, ws_jobs, (int)blockIdx.x - nimg, (int)threadIdx.x);
+        tag_bounds_part(src, tagb, suptag, ws_jobs, (int)blockIdx.x - nimg, (int)threadIdx.x);
         return;
     }
     const int b = blockIdx.x, lane = threadIdx.x, D = 3 + E;
@@ -1027,7 +1047,7 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
 
 hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const float *scores_k, int B, int K, int M, int E,
                         double det_thr, double tag_thr, float *joints, int32_t *num_people, float *ws_tags, int32_t *flags,
-                        const DecodeSrc *bounds_src, float *tagb, int32_t *ws_jobs, hipStream_t s)
+                        const DecodeSrc *bounds_src, float *tagb, unsigned *suptag, int32_t *ws_jobs, hipStream_t s)
 {
     const size_t bytes = ((size_t)K * M * (E + 3) + (size_t)M * (K + 1) * E) * 4;  // candidates + group tag lists
     const int stage = bytes <= 40 * 1024;
@@ -1035,11 +1055,10 @@ hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const floa
     DecodeSrc src{};
     if (bounds_src) {  // + the tag bounds of the refine scans (and the cleared queue counters) in the same launch
         src = *bounds_src;
-        const long long units = (long long)src.B * src.K * (((src.H >> 2) + TBR - 1) / TBR) * (src.W >> 2);
-        extra = (int)((units + 63) / 64);
+        extra = (int)((tag_bounds_units(src.B, src.K, src.H >> 2, src.W >> 2) + 63) / 64);
     }
     hipLaunchKernelGGL(match_kernel, dim3(B + extra), dim3(64), stage ? bytes : 0, s, tags_k, coords_k, scores_k, K, M, E, det_thr, tag_thr,
-                       joints, num_people, ws_tags, flags, stage, B, src, tagb, ws_jobs);
+                       joints, num_people, ws_tags, flags, stage, B, src, tagb, suptag, ws_jobs);
     return hipGetLastError();
 }
 
@@ -1047,14 +1066,13 @@ hipError_t launch_match(const float *tags_k, const int32_t *coords_k, const floa
 // grouping.py:172-191 and :276 (scores = joints[..., 2].mean(1), taken BEFORE refine)
 __global__ __launch_bounds__(256) void adjust_scores_kernel(const DecodeSrc src, int M, int adjust, int refine, float *__restrict__ joints,
                                                             const int32_t *__restrict__ num_people, float *__restrict__ scores,
-                                                            float *__restrict__ ws_prev, int32_t *__restrict__ ws_jobs, int *__restrict__ peaks_ctr)
+                                                            float *__restrict__ ws_prev, int32_t *__restrict__ ws_jobs)
 {
     // + the first step of refine (grouping.py:200-214: the mean tag of a person's detected joints, read at the adjusted
     // coordinates' pixel) and the work lists of the arg-max pass: the tag of every (person, joint) is sampled by the thread that
     // adjusts it -- P * K independent reads instead of one thread per person walking its joints one dependent read after the other
     __shared__ float tl[HH_MAX_PEOPLE * 64 * HH_MAX_EMB];  // [p][k][e]; K <= 64
     const int b = blockIdx.x, tid = threadIdx.x, K = src.K, E = src.E, D = 3 + E;
-    if (b == 0 && tid < 8 && peaks_ctr) peaks_ctr[tid] = 0;  // the work counters of peaks_region_kernel, for the next decode call
     const int P = min(num_people[b], M);
     float *J = joints + (size_t)b * M * K * D;
     for (int i = tid; i < P * K; i += 256) {
@@ -1106,9 +1124,9 @@ __global__ __launch_bounds__(256) void adjust_scores_kernel(const DecodeSrc src,
 }
 
 hipError_t launch_adjust_scores(const DecodeSrc &src, int M, int adjust, int refine, float *joints, const int32_t *num_people, float *scores,
-                                float *ws_prev, int32_t *ws_jobs, int *peaks_ctr, hipStream_t s)
+                                float *ws_prev, int32_t *ws_jobs, hipStream_t s)
 {
-    hipLaunchKernelGGL(adjust_scores_kernel, dim3(src.B), dim3(256), 0, s, src, M, adjust, refine, joints, num_people, scores, ws_prev, ws_jobs, peaks_ctr);
+    hipLaunchKernelGGL(adjust_scores_kernel, dim3(src.B), dim3(256), 0, s, src, M, adjust, refine, joints, num_people, scores, ws_prev, ws_jobs);
     return hipGetLastError();
 }
 

@@ -67,15 +67,16 @@ __device__ long long g_peaks_dbg[4096 * 8];
 #ifndef PEAKS_WPS
 #define PEAKS_WPS 4  // workgroups per CU = waves per SIMD
 #endif
-// Persistent workgroups.  The (image, joint, region) list is cut into 8 contiguous parts, one per XCD (workgroups are dealt to the
-// XCDs round-robin, so blockIdx.x % 8 names one; whole maps per XCD: the halo lines neighbouring regions share go through one L2).
-// A workgroup's first unit is its slot in the part, every further one a ticket from the part's counter `ctr[part]` (zero at launch:
-// adjust_scores_kernel, later in the same decode call, clears it for the next): regions with people in them take 2-3 times as long
-// as empty ones, and a fixed stride gave every workgroup the same region position of each map -- the corner ones finished in half
-// the time of the centre ones.
+// Persistent workgroups.  The (image, joint, region) list is cut into HH_PEAKS_PARTS contiguous parts (fewer when the list or the
+// grid does not divide); workgroup x works on part x % parts, i.e. on an XCD of its own kind (workgroups are dealt to the 8 XCDs
+// round-robin: the halo lines neighbouring regions share go through one L2).  A workgroup's first unit is its slot in the part,
+// every further one a ticket from the part's counter `ctr[part]` (zero at launch; topk_merge_kernel, the next launch, clears it
+// again): regions with people in them take 2-3 times as long as empty ones, and a fixed stride gave every workgroup the same
+// region position of each map -- the corner ones finished in half the time of the centre ones.  64 parts, not 8: a ticket costs
+// what its counter's contention costs (128 workgroups on one counter: 3.5 us each, 16: hidden behind the region's loads).
 __global__ __launch_bounds__(256, PEAKS_WPS) void peaks_region_kernel(const DecodeSrc src, int M, int nrx, int nreg, int nunits, float thr,
                                                                       u64 *__restrict__ cand_key, unsigned short *__restrict__ cellub,
-                                                                      int *__restrict__ ctr)
+                                                                      unsigned short *__restrict__ supmax, int *__restrict__ ctr)
 {
     __shared__ float avgp[HP][AS];
     __shared__ __attribute__((aligned(16))) float hrs[4][HRR][VW];   // per wave: a sub-tile's half-res rows interpolated along x
@@ -90,10 +91,11 @@ __global__ __launch_bounds__(256, PEAKS_WPS) void peaks_region_kernel(const Deco
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = src.H, W = src.W, hh = H >> 1, wh = W >> 1, hq = H >> 2, wq = W >> 2;
     __shared__ int s_next;
-    const bool xcd_split = (nunits % 8 == 0) && (gridDim.x % 8 == 0);
-    const int part = xcd_split ? blockIdx.x % 8 : 0, nwg = xcd_split ? gridDim.x / 8 : gridDim.x;  // this workgroup's part, workgroups on it
-    const int ubase = xcd_split ? part * (nunits / 8) : 0, usize = xcd_split ? nunits / 8 : nunits;
-    int uidx = xcd_split ? blockIdx.x / 8 : blockIdx.x;  // position in the part
+    const int G = gridDim.x;
+    const int nparts = (nunits % HH_PEAKS_PARTS == 0 && G % HH_PEAKS_PARTS == 0) ? HH_PEAKS_PARTS : (nunits % 8 == 0 && G % 8 == 0) ? 8 : 1;
+    const int part = blockIdx.x % nparts, nwg = G / nparts;  // this workgroup's part, workgroups on it
+    const int ubase = part * (nunits / nparts), usize = nunits / nparts;
+    int uidx = blockIdx.x / nparts;  // position in the part
 
     // ---- source samples of one region -> registers.  Wavefront w forms patch rows 18w .. 18w+17 of the lane's column: their 18
     // half-res samples and the 11 quarter-res rows under them at the column's two source columns; the patch's last four columns
@@ -215,6 +217,13 @@ __global__ __launch_bounds__(256, PEAKS_WPS) void peaks_region_kernel(const Deco
             float sm = fmaxf(fmaxf(ub[0], ub[1]), fmaxf(ub[2], ub[3]));
             sm = fmaxf(sm, __shfl_xor(sm, 1));
             sm = fmaxf(sm, __shfl_xor(sm, 2));
+            {   // the largest bound of every 8x8-cell super (2 x 2 sub-tiles: lanes cx .. cx+7 of both cell-row groups of this wavefront):
+                // what the refine scans open a super on.  (Bounds, not the exact maxima the active sub-tiles write below: still upper bounds.)
+                float s8 = fmaxf(sm, __shfl_xor(sm, 4));
+                s8 = fmaxf(s8, __shfl_xor(s8, 32));
+                const int Sy = (Qy0 >> 3) + wv, Sx = (Qx0 >> 3) + (lane >> 3), nsy = (hq + 7) >> 3, nsx = (wq + 7) >> 3;
+                if (lane < 32 && (lane & 7) == 0 && Sy < nsy && Sx < nsx) supmax[((size_t)map * nsy + Sy) * nsx + Sx] = bf16_ceil(s8);
+            }
             // sub-tile (row cyg, column cx >> 2): bit cyg * 8 + (cx >> 2), voted by the lane with cx & 3 == 0
             const bool act = ((cx & 3) == 0) && (Y0 + ST * cyg < H) && (X0 + 4 * cx < W) && !(sm <= thr);
             const u64 bal = __ballot(act);  // lanes 0, 4, .., 28 -> sub-tile row 2 wv, lanes 32, 36, .. -> row 2 wv + 1
@@ -449,7 +458,8 @@ __global__ __launch_bounds__(256, PEAKS_WPS) void peaks_region_kernel(const Deco
 
 int peaks_regions(int H, int W) { return ((H + RG - 1) / RG) * ((W + RG - 1) / RG); }
 
-hipError_t launch_peaks(const DecodeSrc &src, int M, unsigned long long *cand_key, float *cellmax, float thr, int *ctr, hipStream_t s)
+hipError_t launch_peaks(const DecodeSrc &src, int M, unsigned long long *cand_key, float *cellmax, unsigned short *supmax, float thr, int *ctr,
+                        hipStream_t s)
 {
     const int nrx = (src.W + RG - 1) / RG, nreg = peaks_regions(src.H, src.W), nunits = src.B * src.K * nreg;
     static int grid_max = 0;  // PEAKS_WPS 40 KB workgroups per CU
@@ -461,6 +471,6 @@ hipError_t launch_peaks(const DecodeSrc &src, int M, unsigned long long *cand_ke
     }
     const int grid = nunits < grid_max ? nunits : grid_max;
     hipLaunchKernelGGL(peaks_region_kernel, dim3((unsigned)grid), dim3(256), 0, s, src, M, nrx, nreg, nunits, thr, cand_key,
-                       reinterpret_cast<unsigned short *>(cellmax), ctr);
+                       reinterpret_cast<unsigned short *>(cellmax), supmax, ctr);
     return hipGetLastError();
 }

@@ -15,7 +15,11 @@ struct hh_decoder {
     float *avg = nullptr, *cellmax = nullptr, *tagb = nullptr, *cand_val = nullptr, *tags_k = nullptr, *scores_k = nullptr, *ws_tags = nullptr, *ws_prev = nullptr;
     unsigned long long *cand_key = nullptr;
     int32_t *coords_k = nullptr, *flags = nullptr, *ws_jobs = nullptr;  // flags [rB]: HH_DECODE_* bits of the last call
+    unsigned short *supmax = nullptr;  // per 8x8-cell super: heat bound / tag hulls (refine_bb_kernel)
+    unsigned *suptag = nullptr;
+    int rsup = 0;  // supers per map the two hold
     int *pk_ctr = nullptr;  // work counters of the peaks pass: zero between decode calls
+    bool pk_fresh = false;  // just allocated: zeroed on the decode's own stream in front of its first use
     std::vector<void *> allocs;
     int lastB = 0, lastE = 0;
     int exact_topk = 0;   // 1: every tile is processed, so hh_decoder_read_topk returns the reference's full top_k
@@ -25,12 +29,13 @@ struct hh_decoder {
     {
         for (void *p : allocs) hipFree(p);
         allocs.clear();
-        rB = rH = rW = rE = 0;
+        rB = rH = rW = rE = rsup = 0;
     }
     int reserve(int B, int H, int W, int E);
     int run(DecodeSrc &src, int adjust, int refine, float *joints, float *scores, int32_t *num_people, int32_t *flags_out, hipStream_t s);
 };
 
+static int nsup_of(int H, int W) { return ((H / 4 + 7) / 8) * ((W / 4 + 7) / 8); }
 static int ntiles_of(int H, int W)
 {
     return ((H + HH_NMS_TILE - 1) / HH_NMS_TILE) * ((W + HH_NMS_TILE - 1) / HH_NMS_TILE);
@@ -38,7 +43,7 @@ static int ntiles_of(int H, int W)
 
 int hh_decoder::reserve(int B, int H, int W, int E)
 {
-    if (B <= rB && H * W <= rH * rW && ntiles_of(H, W) <= ntiles_of(rH, rW) && E <= rE) return 0;
+    if (B <= rB && H * W <= rH * rW && ntiles_of(H, W) <= ntiles_of(rH, rW) && nsup_of(H, W) <= rsup && E <= rE) return 0;
     const int nB = std::max(B, rB), nH = std::max(H, rH), nW = std::max(W, rW), nE = std::max(E, rE);
     release();
     auto alloc = [&](size_t bytes, void **out) -> int {
@@ -60,9 +65,13 @@ int hh_decoder::reserve(int B, int H, int W, int E)
     if (alloc(((size_t)nB * M * K * 8 + 8) * 4, (void **)&ws_jobs)) return 1;  // 8 counters + 8 job queues (one per XCD)
     if (alloc((size_t)nB * 4, (void **)&flags)) return 1;
     HH_CHECK_HIP(hipMemset(flags, 0, (size_t)nB * 4));
-    if (alloc(64, (void **)&pk_ctr)) return 1;
-    HH_CHECK_HIP(hipMemset(pk_ctr, 0, 64));
-    rB = nB; rH = nH; rW = nW; rE = nE;
+    const int nsup = std::max(std::max(nsup_of(nH, nW), nsup_of(H, W)), rsup);
+    if (alloc((size_t)nB * K * nsup * 2, (void **)&supmax)) return 1;
+    if (alloc((size_t)nB * K * nsup * nE * 4, (void **)&suptag)) return 1;
+    if (alloc(HH_PEAKS_PARTS * 4, (void **)&pk_ctr)) return 1;
+    pk_fresh = true;  // (a hipMemset here runs on the null stream and may still be pending when a non-blocking stream starts the
+                      // first launch: counters that are not zero make the persistent grid skip regions)
+    rB = nB; rH = nH; rW = nW; rE = nE; rsup = nsup;
     return 0;
 }
 
@@ -80,26 +89,31 @@ int hh_decoder::run(DecodeSrc &src, int adjust, int refine, float *joints, float
     if (skip) {
         // default path (round 4): one pass over the net's outputs forms the stage average in LDS, finds the peaks above det_thr and
         // leaves the cell bounds of the refine scans; the averaged map is not written (src.avg stays null: readers form its values)
-        HH_CHECK_HIP(launch_peaks(src, M, cand_key, cellmax, thr_f, pk_ctr, s));
-        HH_CHECK_HIP(launch_topk_merge(src, M, peaks_regions(src.H, src.W), cand_key, nullptr, tags_k, coords_k, scores_k, s));
+        if (pk_fresh) {
+            HH_CHECK_HIP(hipMemsetAsync(pk_ctr, 0, HH_PEAKS_PARTS * 4, s));
+            pk_fresh = false;
+        }
+        HH_CHECK_HIP(launch_peaks(src, M, cand_key, cellmax, supmax, thr_f, pk_ctr, s));
+        HH_CHECK_HIP(launch_topk_merge(src, M, peaks_regions(src.H, src.W), cand_key, nullptr, tags_k, coords_k, scores_k, pk_ctr, s));
     } else {
         if (src.mode == 0) {
             HH_CHECK_HIP(launch_stage_average(src.hm_q, src.hm_q_bs, src.hm_h, src.hm_h_bs, avg, src.B, K, src.H / 4, src.W / 4, s));
             src.avg = avg;
         }
         HH_CHECK_HIP(launch_nms_tile_topk(src, M, cand_key, cand_val, cellmax, -INFINITY, s));
-        HH_CHECK_HIP(launch_topk_merge(src, M, ntiles_of(src.H, src.W), cand_key, cand_val, tags_k, coords_k, scores_k, s));
+        HH_CHECK_HIP(launch_topk_merge(src, M, ntiles_of(src.H, src.W), cand_key, cand_val, tags_k, coords_k, scores_k, nullptr, s));
     }
     last_exact = !skip;
     // (mode 0: the tag bounds of the refine scans and the cleared queue counters ride in the matching launch)
     const bool bounds = refine && src.mode == 0;
     if (refine && !bounds) HH_CHECK_HIP(hipMemsetAsync(ws_jobs, 0, 32, s));  // the 8 queue counters
     HH_CHECK_HIP(launch_match(tags_k, coords_k, scores_k, src.B, K, M, src.E, det_thr, tag_thr, joints, num_people, ws_tags, flags_out ? flags_out : flags,
-                              bounds ? &src : nullptr, tagb, ws_jobs, s));
+                              bounds ? &src : nullptr, tagb, skip ? suptag : nullptr, ws_jobs, s));
     flags_last = flags_out ? flags_out : flags;
     if (skip) HH_CHECK_HIP(launch_fallback_top1(src, M, flags_last, joints, s));
-    HH_CHECK_HIP(launch_adjust_scores(src, M, adjust, refine, joints, num_people, scores, ws_prev, ws_jobs, pk_ctr, s));
-    if (refine) HH_CHECK_HIP(launch_refine(src, M, joints, ws_prev, ws_jobs, cellmax, tagb, s));
+    HH_CHECK_HIP(launch_adjust_scores(src, M, adjust, refine, joints, num_people, scores, ws_prev, ws_jobs, s));
+    if (refine && skip) HH_CHECK_HIP(launch_refine_bb(src, M, joints, ws_prev, ws_jobs, cellmax, tagb, supmax, suptag, s));
+    else if (refine) HH_CHECK_HIP(launch_refine(src, M, joints, ws_prev, ws_jobs, cellmax, tagb, s));
     lastB = src.B; lastE = src.E;
     return 0;
 }

@@ -30,6 +30,15 @@ class _ResBox:
         self.g = None
 
 
+def _box_put(box, g) -> None:
+    """The last BatchNorm's backward leaves the unit's skip gradient for the first conv's backward; a gradient still waiting there belongs
+    to a backward whose first conv never ran (a partial torch.autograd.grad) and must not be added to this one."""
+    if box.g is not None:
+        raise RuntimeError("train_net: a stale skip gradient is still waiting for its unit's first convolution (a previous backward did not "
+                           "reach it); HH_TRAIN_NO_RESBOX=1 routes the skip gradient through autograd instead")
+    box.g = g
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, stride: int, pad, packed_fwd=None, packed_bwd=None, box=None):
@@ -43,6 +52,9 @@ class _ConvFn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         skip = None
         if ctx.box is not None:  # the unit's skip gradient (left there by its last BatchNorm's backward, which has run)
+            if ctx.box.g is None:  # e.g. torch.autograd.grad towards inputs the last BatchNorm does not reach: the skip path would be dropped silently
+                raise RuntimeError("train_net: the residual unit's skip gradient is missing (its last BatchNorm's backward has not run); "
+                                   "HH_TRAIN_NO_RESBOX=1 routes it through autograd instead")
             skip, ctx.box.g = ctx.box.g, None
         dx = ops.conv2d(dy, w, ctx.stride, data_grad=True, pad=ctx.pad, packed=ctx.packed_bwd, res=skip) if ctx.needs_input_grad[0] else None
         dw = ops.conv2d_weight_grad(x, dy, w.shape[-1], ctx.stride, pad=ctx.pad) if ctx.needs_input_grad[1] else None
@@ -74,7 +86,8 @@ class _BNFn(torch.autograd.Function):
             dx, dgamma, dbeta, dres = ops.sync_bn_train_backward(x, y, dy.contiguous(memory_format=torch.channels_last), mean, invstd,
                                                                  gamma, ctx.relu, ctx.has_res, ctx.sync[0], ctx.count)
             if ctx.box is not None:
-                ctx.box.g, dres = dres, None
+                _box_put(ctx.box, dres)
+                dres = None
             return dx, dgamma, dbeta, dres, None, None, None, None
         if ctx.plain:  # (y holds beta)
             dx, dgamma, dbeta, dres = ops.bn_train_backward(x, None, dy.contiguous(memory_format=torch.channels_last), mean, invstd, gamma,
@@ -83,7 +96,8 @@ class _BNFn(torch.autograd.Function):
             dx, dgamma, dbeta, dres = ops.bn_train_backward(x, y, dy.contiguous(memory_format=torch.channels_last), mean, invstd, gamma,
                                                             ctx.relu, want_dres=ctx.has_res)
         if ctx.box is not None:
-            ctx.box.g, dres = dres, None
+            _box_put(ctx.box, dres)
+            dres = None
         return dx, dgamma, dbeta, dres, None, None, None, None
 
 

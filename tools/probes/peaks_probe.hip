@@ -51,22 +51,23 @@ int main(int argc, char **argv)
     hipMalloc(&ck, (size_t)B * K * nreg * M * 8); hipMalloc(&cm, (size_t)B * K * hq * wq * 4);
     const size_t fl = 512u << 20;  // a 512 MiB fill between launches: the sources come from HBM, as behind a forward pass
     hipMalloc(&flush, fl);
-    int *ctr; hipMalloc(&ctr, 64);
+    int *ctr; hipMalloc(&ctr, HH_PEAKS_PARTS * 4);
+    unsigned short *sup; hipMalloc(&sup, (size_t)B * K * 1024 * 2);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float tot = 0.f, warm = 0.f;
     for (int i = 0; i < 8; ++i) {
         hipMemsetAsync(flush, i, fl, 0);
-        hipMemsetAsync(ctr, 0, 64, 0);
+        hipMemsetAsync(ctr, 0, HH_PEAKS_PARTS * 4, 0);
         hipEventRecord(e0, 0);
-        launch_peaks(src, M, ck, cm, 0.05f, ctr, 0);
+        launch_peaks(src, M, ck, cm, sup, 0.05f, ctr, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (i >= 3) tot += ms;
     }
     for (int i = 0; i < 5; ++i) {
-        hipMemsetAsync(ctr, 0, 64, 0);
+        hipMemsetAsync(ctr, 0, HH_PEAKS_PARTS * 4, 0);
         hipEventRecord(e0, 0);
-        launch_peaks(src, M, ck, cm, 0.05f, ctr, 0);
+        launch_peaks(src, M, ck, cm, sup, 0.05f, ctr, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         warm += ms;

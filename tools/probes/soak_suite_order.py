@@ -39,7 +39,6 @@ params = [("w32_128", 32, 2, 128, 128, 1), ("w32_96x160", 32, 1, 96, 160, 2), ("
 order = [
     lambda: t.test_forward_with_taps_vs_reference_golden(pkg, golden),
     *[functools.partial(t.test_forward_outputs_vs_reference_golden, pkg, golden, *p) for p in params],
-    lambda: t.test_fused_128_channel_block_opt_in(pkg, golden),
     lambda: t.test_fused_32_channel_block_both_forms(pkg, golden),
     lambda: t.test_fused_stem_matches_two_launches(pkg, golden),
     lambda: t.test_schedule_and_fusion_switches(pkg, golden),
