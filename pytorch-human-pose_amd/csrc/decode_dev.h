@@ -8,6 +8,13 @@
 
 typedef unsigned long long u64;
 
+// element idx of a wave-uniform plane: the byte offset stays 32-bit (planes are < 2^24 pixels), so the load takes the scalar-base +
+// vector-offset form and needs one address register, not a 64-bit pair
+__device__ __forceinline__ float ldg(const float *__restrict__ base, int idx)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (unsigned)(idx << 2));
+}
+
 // ------------------------------------------------------------------ bilinear sampling
 // F.interpolate(mode="bilinear", align_corners=False), torch CPU fp32 (results.py:48-67)
 struct Lin { int i0, i1; float w0, w1; };
@@ -53,6 +60,53 @@ __device__ __forceinline__ float heat_at(const DecodeSrc &s, int b, int k, int y
     const float c = __builtin_fmaf(avg_at(s, b, k, ly.i1, lx.i0), lx.w0, avg_at(s, b, k, ly.i1, lx.i1) * lx.w1);
     return __builtin_fmaf(a, ly.w0, c * ly.w1);
 }
+// N full-resolution heat values of map (b, k) at once on the default path (mode 0, no materialised stage average): every sample is
+// 4 averaged taps x (4 quarter-res + 1 half-res) loads, and asked for one after the other through heat_at() (whose mode switches are
+// run-time branches) each of them is a memory round trip of its own; here the 20 N loads are all issued before the first use.
+// Same expressions as heat_at() / avg_at() per value.
+template <int N>
+__device__ __forceinline__ void heat_otf(const DecodeSrc &s, int b, int k, const int (&ys)[N], const int (&xs)[N], float (&out)[N])
+{
+    const int hq = s.H >> 2, wq = s.W >> 2, hh = s.H >> 1, wh = s.W >> 1;
+    const float *q = s.hm_q + (size_t)b * s.hm_q_bs + (size_t)k * hq * wq;
+    const float *h = s.hm_h + (size_t)b * s.hm_h_bs + (size_t)k * hh * wh;
+    Lin ly[N], lx[N], qy[N][2], qx[N][2];
+    float qv[N][2][2][4], hv[N][2][2];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        ly[n] = src_index(hh, s.scale_h2, ys[n]); lx[n] = src_index(wh, s.scale_w2, xs[n]);
+        qy[n][0] = src_index(hq, 0.5f, ly[n].i0); qy[n][1] = src_index(hq, 0.5f, ly[n].i1);
+        qx[n][0] = src_index(wq, 0.5f, lx[n].i0); qx[n][1] = src_index(wq, 0.5f, lx[n].i1);
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const Lin &ry = qy[n][a], &rx = qx[n][c];
+                qv[n][a][c][0] = ldg(q, ry.i0 * wq + rx.i0); qv[n][a][c][1] = ldg(q, ry.i0 * wq + rx.i1);
+                qv[n][a][c][2] = ldg(q, ry.i1 * wq + rx.i0); qv[n][a][c][3] = ldg(q, ry.i1 * wq + rx.i1);
+                hv[n][a][c] = ldg(h, (a ? ly[n].i1 : ly[n].i0) * wh + (c ? lx[n].i1 : lx[n].i0));
+            }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        float av[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const Lin &ry = qy[n][a], &rx = qx[n][c];
+                const float u0 = __builtin_fmaf(qv[n][a][c][0], rx.w0, qv[n][a][c][1] * rx.w1);
+                const float u1 = __builtin_fmaf(qv[n][a][c][2], rx.w0, qv[n][a][c][3] * rx.w1);
+                av[a][c] = (__builtin_fmaf(u0, ry.w0, u1 * ry.w1) + hv[n][a][c]) / 2.0f;
+            }
+        const float t0 = __builtin_fmaf(av[0][0], lx[n].w0, av[0][1] * lx[n].w1);
+        const float t1 = __builtin_fmaf(av[1][0], lx[n].w0, av[1][1] * lx[n].w1);
+        out[n] = __builtin_fmaf(t0, ly[n].w0, t1 * ly[n].w1);
+    }
+}
+
 __device__ __forceinline__ float tag_at(const DecodeSrc &s, int b, int k, int y, int x, int e)
 {
     if (s.mode == 1) return s.tags_full[((((size_t)b * s.K + k) * s.H + y) * s.W + x) * s.E + e];

@@ -699,18 +699,41 @@ __device__ int munkres_wave_n(MatchShared &S, int n, int lane, int &star)
 {
     // step 1: subtract the row minimum (lane = row).  The row is read into registers in one go (a rolled loop waits for LDS once
     // per element), reduced there and written back.
-    if (lane < n) {
+    const unsigned nmask = n >= 32 ? 0xffffffffu : (1u << n) - 1u;  // lanes / rows / columns of the problem
+    {
         double rowv[NMAX];
+        unsigned rz = 0;  // the zeros step 1 leaves in row `lane`: the columns that hold the row minimum
+        if (lane < n) {
 #pragma unroll
-        for (int j = 0; j < NMAX; ++j) rowv[j] = S.Cm[lane * MLD + (j < n ? j : 0)];
-        double mn = rowv[0];
+            for (int j = 0; j < NMAX; ++j) rowv[j] = S.Cm[lane * MLD + (j < n ? j : 0)];
+            double mn = rowv[0];
 #pragma unroll
-        for (int j = 1; j < NMAX; ++j) if (j < n && rowv[j] < mn) mn = rowv[j];
+            for (int j = 1; j < NMAX; ++j) if (j < n && rowv[j] < mn) mn = rowv[j];
 #pragma unroll
-        for (int j = 0; j < NMAX; ++j) if (j < n) S.Cm[lane * MLD + j] = rowv[j] - mn;
+            for (int j = 0; j < NMAX; ++j) {
+                rowv[j] = rowv[j] - mn;
+                rz |= (j < n && rowv[j] == 0.0) ? (1u << j) : 0u;
+            }
+        }
+        // Round 4: steps 2 and 3 straight from these masks.  If step 2 stars every row, step 3 finds every column covered and the
+        // solver is done with exactly these stars -- the usual case on separable tags -- without the matrix write-back, the column
+        // fetch and the per-row ballots that rebuild the same masks below (a third of a call's prologue).
+        unsigned cc0 = 0;
+        int sc0 = -1;
+        for (int i = 0; i < n; ++i) {
+            const unsigned z = readlane_u32(rz, i) & ~cc0;
+            if (z) {
+                const int j = __builtin_ctz(z);
+                sc0 = setlane_i32(j, i, sc0, lane);
+                cc0 |= 1u << j;
+            }
+        }
+        if (__popc(cc0 & nmask) >= n) { star = sc0; return 0; }
+        if (lane < n)
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) if (j < n) S.Cm[lane * MLD + j] = rowv[j];
     }
     __syncthreads();
-    const unsigned nmask = n >= 32 ? 0xffffffffu : (1u << n) - 1u;  // lanes / rows / columns of the problem
     double col[NMAX];  // column `lane`
     int myz = 0;       // zeros of row `lane` (bit j = column j)
     unsigned zt = 0;   // zeros of column `lane` (bit i = row i)
@@ -1072,38 +1095,75 @@ __global__ __launch_bounds__(256) void adjust_scores_kernel(const DecodeSrc src,
     // coordinates' pixel) and the work lists of the arg-max pass: the tag of every (person, joint) is sampled by the thread that
     // adjusts it -- P * K independent reads instead of one thread per person walking its joints one dependent read after the other
     __shared__ float tl[HH_MAX_PEOPLE * 64 * HH_MAX_EMB];  // [p][k][e]; K <= 64
+    __shared__ float sl[HH_MAX_PEOPLE * 64];               // [p][k]: the joints' scores (the per-person loops below walk them here:
+                                                           // from global memory each step was a dependent round trip, 2 K of them)
     const int b = blockIdx.x, tid = threadIdx.x, K = src.K, E = src.E, D = 3 + E;
     const int P = min(num_people[b], M);
     float *J = joints + (size_t)b * M * K * D;
     for (int i = tid; i < P * K; i += 256) {
         float *j = J + (size_t)i * D;
         const int k = i % K;
+        sl[i] = j[2];
         if (j[2] == 0.f) continue;
         float x = j[0], y = j[1];
         const int xi = (int)x, yi = (int)y;
+        // the four heat samples and the tag sample(s) are independent reads -- the tag is read at the pixel of the ADJUSTED coordinates
+        // (grouping.py:206-207), which is (yi, xi) again: the candidate's integer coordinate +- 0.25 + 0.5 truncates back to it --,
+        // so all of them are in flight before the first comparison (each heat sample is twenty loads behind index arithmetic)
+        float hs[4] = {0.f, 0.f, 0.f, 0.f}, tg[HH_MAX_EMB] = {0.f, 0.f, 0.f, 0.f};
+        const bool want_tag = refine && j[2] > 0.f;
+        // (one embedding, the usual case: the four taps are only LOADED here -- bilerp()'s arithmetic follows behind the heat samples'
+        // loads, so the two groups share one memory round trip; more embeddings take tag_at() one after the other)
+        const bool tag1 = refine && E == 1 && src.mode == 0;
+        float tt[4] = {0.f, 0.f, 0.f, 0.f};
+        Lin tly{}, tlx{};
+        if (tag1) {
+            const int hq = src.H >> 2, wq = src.W >> 2;
+            const float *tq = src.tags_q[0] + (size_t)b * src.tags_bs[0] + (size_t)k * hq * wq;
+            tly = src_index(hq, src.scale_h4, yi); tlx = src_index(wq, src.scale_w4, xi);
+            tt[0] = ldg(tq, tly.i0 * wq + tlx.i0); tt[1] = ldg(tq, tly.i0 * wq + tlx.i1);
+            tt[2] = ldg(tq, tly.i1 * wq + tlx.i0); tt[3] = ldg(tq, tly.i1 * wq + tlx.i1);
+        } else if (refine) {
+#pragma unroll
+            for (int e = 0; e < HH_MAX_EMB; ++e)
+                if (e < E) tg[e] = tag_at(src, b, k, yi, xi, e);
+        }
         if (adjust) {
             const int xr = min(xi + 1, src.W - 1), xl = max(xi - 1, 0), yd = min(yi + 1, src.H - 1), yu = max(yi - 1, 0);
-            if (heat_at(src, b, k, yi, xr) > heat_at(src, b, k, yi, xl)) x += 0.25f; else x -= 0.25f;
-            if (heat_at(src, b, k, yd, xi) > heat_at(src, b, k, yu, xi)) y += 0.25f; else y -= 0.25f;
+            if (src.mode == 0 && !src.avg) {
+                const int ys[4] = {yi, yi, yd, yu}, xs[4] = {xr, xl, xi, xi};
+                heat_otf<4>(src, b, k, ys, xs, hs);
+            } else {
+                hs[0] = heat_at(src, b, k, yi, xr); hs[1] = heat_at(src, b, k, yi, xl);
+                hs[2] = heat_at(src, b, k, yd, xi); hs[3] = heat_at(src, b, k, yu, xi);
+            }
+        }
+        if (adjust) {
+            if (hs[0] > hs[1]) x += 0.25f; else x -= 0.25f;
+            if (hs[2] > hs[3]) y += 0.25f; else y -= 0.25f;
             x += 0.5f; y += 0.5f;
             j[0] = x; j[1] = y;
         }
-        if (refine && j[2] > 0.f) {
-            const int xt = (int)x, yt = (int)y;  // grouping.py:206-207: the pixel of the (adjusted) coordinates
-            for (int e = 0; e < E; ++e) tl[i * E + e] = tag_at(src, b, k, yt, xt, e);
+        if (tag1) {  // bilerp(): rows along x, then along y
+            const float a = __builtin_fmaf(tt[0], tlx.w0, tt[1] * tlx.w1), c = __builtin_fmaf(tt[2], tlx.w0, tt[3] * tlx.w1);
+            tg[0] = __builtin_fmaf(a, tly.w0, c * tly.w1);
         }
+        if (want_tag)
+#pragma unroll
+            for (int e = 0; e < HH_MAX_EMB; ++e)
+                if (e < E) tl[i * E + e] = tg[e];
     }
     __syncthreads();
     for (int p = tid; p < M; p += 256)
-        scores[(size_t)b * M + p] = p < P ? __fdiv_rn(np_sum_f32(J + (size_t)p * K * D + 2, K, D), (float)K) : 0.f;
+        scores[(size_t)b * M + p] = p < P ? __fdiv_rn(np_sum_f32(sl + (size_t)p * K, K, 1), (float)K) : 0.f;
     if (!refine || tid >= P) return;
     {
         const int p = tid;
-        const float *Jp = J + (size_t)p * K * D;
+        const float *Sp = sl + (size_t)p * K;
         float *mine = tl + (size_t)p * K * E;  // compacted in place, in joint order (the write index never passes the read index)
         int nt = 0;
         for (int k = 0; k < K; ++k)
-            if (Jp[k * D + 2] > 0.f) {
+            if (Sp[k] > 0.f) {
                 for (int e = 0; e < E; ++e) mine[nt * E + e] = mine[k * E + e];
                 ++nt;
             }
@@ -1116,7 +1176,7 @@ __global__ __launch_bounds__(256) void adjust_scores_kernel(const DecodeSrc src,
         // map's cell maxima / tag bounds out of the same L2 instead of fetching them once per XCD.
         const int cap = gridDim.x * M * K;  // queue capacity = every (b, p, k)
         for (int k = 0; k < K; ++k)
-            if (Jp[k * D + 2] == 0.f) {
+            if (Sp[k] == 0.f) {
                 const int qx = (b * K + k) & 7;
                 ws_jobs[8 + qx * cap + atomicAdd(ws_jobs + qx, 1)] = (b << 16) | (p << 8) | k;
             }

@@ -43,13 +43,6 @@ static_assert(NS * NS == 64, "the sub-tile activity mask is one 64-lane ballot")
 __device__ __forceinline__ float wlo(int D, int n) { return (D & 1) ? (((D >> 1) + 1 > n - 1) ? 1.f : 0.75f) : (D <= 0 ? 0.f : 0.25f); }
 __device__ __forceinline__ float whi(int D, int n) { return (D & 1) ? (((D >> 1) + 1 > n - 1) ? 0.f : 0.25f) : (D <= 0 ? 1.f : 0.75f); }
 
-// element idx of a wave-uniform plane: the byte offset stays 32-bit (planes are < 2^24 pixels), so the load takes the scalar-base +
-// vector-offset form and needs one address register, not a 64-bit pair
-__device__ __forceinline__ float ldg(const float *__restrict__ base, int idx)
-{
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (unsigned)(idx << 2));
-}
-
 // orders the LDS traffic of ONE wavefront (its ds instructions execute in issue order; the compiler must not move them)
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 

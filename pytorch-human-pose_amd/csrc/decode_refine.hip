@@ -45,12 +45,12 @@ struct CellEval {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) t9[r][c] = q[yq[r] + xq[c]];
+                for (int c = 0; c < 3; ++c) t9[r][c] = ldg(q, yq[r] + xq[c]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int yo = min(max(2 * qy - 1 + i, 0), hh - 1) * wh;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) h16[i][j] = h[yo + min(max(2 * qx - 1 + j, 0), wh - 1)];
+                for (int j = 0; j < 4; ++j) h16[i][j] = ldg(h, yo + min(max(2 * qx - 1 + j, 0), wh - 1));
             }
             float uph[3][4];
 #pragma unroll
@@ -95,7 +95,7 @@ struct CellEval {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) t9[r][c] = t[yq[r] + xq[c]];
+                for (int c = 0; c < 3; ++c) t9[r][c] = ldg(t, yq[r] + xq[c]);
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) {
                 const bool first = qx == 0 && jx < 2;  // source position below 0: torch reads sample 0 with weight 1
@@ -155,18 +155,19 @@ __device__ __forceinline__ float bound_of(unsigned short hb, const unsigned *__r
 
 }  // namespace
 
-#ifndef REFINE_WPS
-#define REFINE_WPS 3  // workgroups per CU (148 registers: 4 would spill)
-#endif
-__global__ __launch_bounds__(256, REFINE_WPS) void refine_bb_kernel(const DecodeSrc src, int M, const int32_t *__restrict__ ws_jobs,
+#ifndef REFINE_THREADS
+#define REFINE_THREADS 128  // per job.  The evaluation needs ~160 registers, i.e. 3 wavefronts per SIMD: with 256-thread workgroups 768 jobs
+#endif                      // run at once and the bench's ~900 take two rounds; with 128 threads 1536 do, each a little slower
+constexpr int RT = REFINE_THREADS, RW = RT / 64;
+__global__ __launch_bounds__(RT, 3) void refine_bb_kernel(const DecodeSrc src, int M, const int32_t *__restrict__ ws_jobs,
                                                            const float *__restrict__ ws_prev, const unsigned short *__restrict__ cellub,
                                                            const unsigned *__restrict__ tagb, const unsigned short *__restrict__ supmax,
                                                            const unsigned *__restrict__ suptag, float *__restrict__ joints)
 {
-    __shared__ u64 wbest[4];
-    __shared__ int sdone[4];
+    __shared__ u64 wbest[RW];
+    __shared__ int sdone[RW];
     __shared__ unsigned clist[RCAP];
-    __shared__ int ncl;
+    __shared__ int ncl, ovf;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, E = src.E;
     const int hq = src.H >> 2, wq = src.W >> 2, nsy = (hq + 7) >> 3, nsx = (wq + 7) >> 3, nsup = nsy * nsx;
     // persistent grid; workgroup x runs on XCD x % 8 (round-robin dispatch, grid a multiple of 8) and serves queue x % 8: the
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256, REFINE_WPS) void refine_bb_kernel(const Decode
     const int njobs = ws_jobs[qxi];
     for (int job = blockIdx.x >> 3; job < njobs; job += gridDim.x >> 3) {
         const int code = ws_jobs[8 + qxi * cap + job];
-        const int b = code >> 16, p = (code >> 8) & 0xff, k = code & 0xff;
+        const int b = __builtin_amdgcn_readfirstlane(code >> 16), p = __builtin_amdgcn_readfirstlane((code >> 8) & 0xff), k = __builtin_amdgcn_readfirstlane(code & 0xff);
         const float *prev = ws_prev + ((size_t)b * M + p) * (HH_MAX_EMB + 1);
         float mean[HH_MAX_EMB];
         for (int e = 0; e < E; ++e) mean[e] = prev[e];
@@ -183,87 +184,136 @@ __global__ __launch_bounds__(256, REFINE_WPS) void refine_bb_kernel(const Decode
         const unsigned short *cm = cellub + map * hq * wq, *sm = supmax + map * nsup;
         const unsigned *tb = tagb + map * hq * wq * E, *st = suptag + map * nsup * E;
         CellEval ev{src, b, k, E, mean, 0ull};
-        if (tid == 0) ncl = 0;
-
-        // ---- A. the wavefront's most promising super, every cell of it evaluated (a lane per cell)
-        {
-            float bs = -INFINITY;
-            int bi = -1;
-            for (int s = tid; s < nsup; s += 256) {
-                const float su = bound_of(sm[s], st + (size_t)s * E, E, mean);
-                if (su > bs || bi < 0) { bs = su; bi = s; }
-            }
-            const u64 wk = wave_max_u64(bi >= 0 ? make_key(bs, (unsigned)bi) : 0ull);
-            int s0 = -1;
-            if (wk) {  // wave-uniform
-                s0 = (int)(0xffffffffu - (unsigned)(wk & 0xffffffffull));
-                const int qy = 8 * (s0 / nsx) + (lane >> 3), qx = 8 * (s0 % nsx) + (lane & 7);
-                if (qy < hq && qx < wq) ev(qy, qx);
-            }
-            const u64 wb = wave_max_u64(ev.best);
-            if (lane == 0) { wbest[wv] = wb; sdone[wv] = s0; }
-        }
-        __syncthreads();
-        u64 g = wbest[0];
-        for (int w = 1; w < 4; ++w) g = wbest[w] > g ? wbest[w] : g;
-        unsigned gb = (unsigned)(g >> 32);  // invert make_key's order-preserving map
-        gb = (gb & 0x80000000u) ? (gb & 0x7fffffffu) : ~gb;
-        const float bound = __uint_as_float(gb);  // (every map has a super, every super a cell: g != 0)
-        const int d0 = sdone[0], d1 = sdone[1], d2 = sdone[2], d3 = sdone[3];
-
-        // ---- B. supers whose bound reaches it are opened: cells whose bound reaches it go to the list (or, list full, are evaluated here)
-        for (int s0 = 0; s0 < nsup; s0 += 256) {
-            const int s = s0 + tid;
-            bool alive = false;
-            if (s < nsup && s != d0 && s != d1 && s != d2 && s != d3) alive = bound_of(sm[s], st + (size_t)s * E, E, mean) >= bound;
-            for (u64 m = __ballot(alive); m; m &= m - 1) {
-                const int ss = s0 + wv * 64 + __builtin_ctzll(m);
-                const int qy = 8 * (ss / nsx) + (lane >> 3), qx = 8 * (ss % nsx) + (lane & 7);
-                const int c = qy * wq + qx;
-                bool surv = false;
-                // (the heat bound alone rejects most cells: the tag hull is only read behind it)
-                if (qy < hq && qx < wq && !(__uint_as_float((unsigned)cm[c] << 16) < bound)) surv = bound_of(cm[c], tb + (size_t)c * E, E, mean) >= bound;
-                const u64 smk = __ballot(surv);
-                if (smk) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&ncl, __popcll(smk));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    const int pos = base + __popcll(smk & ((1ull << lane) - 1ull));
-                    if (surv) {
-                        if (pos < RCAP) clist[pos] = (unsigned)c;
-                        else ev(qy, qx);
+        if (tid == 0) { ncl = 0; ovf = 0; }
+        float bound = 0.f;
+        int dn[RW];
+#pragma unroll
+        for (int w = 0; w < RW; ++w) dn[w] = -1;
+        // Two rounds over ONE evaluation loop (the evaluation is ~400 instructions and 100+ registers: one copy of it):
+        //   round 0: every wavefront lists the 64 cells of its most promising super; the best value found is the lower bound B;
+        //   round 1: supers whose bound reaches B are opened, cells whose bound reaches B are listed.
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            if (round == 0) {
+                float bs = -INFINITY;
+                int bi = -1;
+                for (int s = tid; s < nsup; s += RT) {
+                    const float su = bound_of(sm[s], st + (size_t)s * E, E, mean);
+                    if (su > bs || bi < 0) { bs = su; bi = s; }
+                }
+                const u64 wk = wave_max_u64(bi >= 0 ? make_key(bs, (unsigned)bi) : 0ull);
+                int s0 = -1;
+                unsigned cell = ~0u;
+                if (wk) {  // wave-uniform
+                    s0 = (int)(0xffffffffu - (unsigned)(wk & 0xffffffffull));
+                    const int qy = 8 * (s0 / nsx) + (lane >> 3), qx = 8 * (s0 % nsx) + (lane & 7);
+                    if (qy < hq && qx < wq) cell = ((unsigned)qy << 16) | (unsigned)qx;
+                }
+                clist[tid] = cell;
+                if (lane == 0) sdone[wv] = s0;
+            } else {
+                // Four supers per step: a step is two dependent load rounds (heat bounds, then tag hulls behind them), and a wavefront
+                // that takes its supers one at a time waits for every one of them in turn.
+                for (int s0 = 0; s0 < nsup; s0 += RT) {
+                    const int s = s0 + tid;
+                    bool alive = false;
+                    if (s < nsup) {
+                        alive = true;
+#pragma unroll
+                        for (int w = 0; w < RW; ++w) alive = alive && s != dn[w];
+                        if (alive) alive = bound_of(sm[s], st + (size_t)s * E, E, mean) >= bound;
+                    }
+                    u64 m = __ballot(alive);
+                    while (m) {
+                        int cc[4];
+                        unsigned pk[4];
+                        unsigned short hb[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            cc[u] = -1; hb[u] = 0; pk[u] = ~0u;
+                            if (m) {  // (wave-uniform)
+                                const int ss = s0 + wv * 64 + __builtin_ctzll(m);
+                                m &= m - 1;
+                                const int qy = 8 * (ss / nsx) + (lane >> 3), qx = 8 * (ss % nsx) + (lane & 7);
+                                if (qy < hq && qx < wq) { cc[u] = qy * wq + qx; pk[u] = ((unsigned)qy << 16) | (unsigned)qx; }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (cc[u] >= 0) hb[u] = cm[cc[u]];
+                        bool surv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            // (the heat bound alone rejects most cells: the tag hull is only read behind it)
+                            surv[u] = cc[u] >= 0 && !(__uint_as_float((unsigned)hb[u] << 16) < bound);
+                            if (surv[u]) surv[u] = bound_of(hb[u], tb + (size_t)cc[u] * E, E, mean) >= bound;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const u64 smk = __ballot(surv[u]);
+                            if (smk) {
+                                int base = 0;
+                                if (lane == 0) base = atomicAdd(&ncl, __popcll(smk));
+                                base = __builtin_amdgcn_readfirstlane(base);
+                                const int pos = base + __popcll(smk & ((1ull << lane) - 1ull));
+                                if (surv[u]) {
+                                    if (pos < RCAP) clist[pos] = pk[u];
+                                    else ovf = 1;  // (does not happen on real maps: thousands of cells tie with the bound)
+                                }
+                            }
+                        }
                     }
                 }
             }
-        }
-        __syncthreads();
-        // ---- C. the listed cells, 256 at a time
-        {
-            const int n = min(ncl, RCAP);
-            for (int i = tid; i < n; i += 256) {
-                const int c = (int)clist[i];
-                ev(c / wq, c % wq);
+            __syncthreads();
+            const int n = round == 0 ? RT : min(ncl, RCAP);
+            for (int i = tid; i < n; i += RT) {
+                const unsigned c = clist[i];
+                if (c != ~0u) ev((int)(c >> 16), (int)(c & 0xffffu));
+            }
+            const u64 wb = wave_max_u64(ev.best);
+            if (round) __syncthreads();  // (round 0's wbest was read by everybody before round 1's list was complete)
+            if (lane == 0) wbest[wv] = wb;
+            __syncthreads();
+            if (round == 0) {
+                u64 g = wbest[0];
+                for (int w = 1; w < RW; ++w) g = wbest[w] > g ? wbest[w] : g;
+                unsigned gb = (unsigned)(g >> 32);  // invert make_key's order-preserving map
+                gb = (gb & 0x80000000u) ? (gb & 0x7fffffffu) : ~gb;
+                bound = __uint_as_float(gb);  // (every map has a super, every super a cell: g != 0)
+                #pragma unroll
+                for (int w = 0; w < RW; ++w) dn[w] = sdone[w];
             }
         }
-        const u64 wb2 = wave_max_u64(ev.best);
-        __syncthreads();  // (wbest was read above)
-        if (lane == 0) wbest[wv] = wb2;
-        __syncthreads();
-        if (tid == 0) {
+        if (ovf) {  // (block-uniform: read behind the barriers above) the list was too short: every cell whose bound reaches B, where it stands
+            for (int c = tid; c < hq * wq; c += RT)
+                if (bound_of(cm[c], tb + (size_t)c * E, E, mean) >= bound) ev(c / wq, c % wq);
+            const u64 wb = wave_max_u64(ev.best);
+            __syncthreads();
+            if (lane == 0) wbest[wv] = wb;
+            __syncthreads();
+        }
+        if (wv == 0) {
             u64 gg = wbest[0];
-            for (int w = 1; w < 4; ++w) gg = wbest[w] > gg ? wbest[w] : gg;
+            for (int w = 1; w < RW; ++w) gg = wbest[w] > gg ? wbest[w] : gg;
             // grouping.py:238-249: the joint is filled in if the heat value at the arg-max is positive (it had score 0: only such joints
             // are queued), with the quarter-pixel shift of `adjust` in float64 as numpy computes it.  Nothing else reads or writes this
-            // joint's slot, so the job's own workgroup applies it.
-            if (gg != 0ull) {
-                float *j = joints + (((size_t)b * M + p) * src.K + k) * (3 + E);
+            // joint's slot, so the job's own workgroup applies it.  The five heat samples (the pixel, right, left, below, above) are
+            // formed by five lanes side by side: each is twenty loads behind a chain of index arithmetic.
+            if (gg != 0ull) {  // (wave-uniform)
                 const unsigned idx = 0xffffffffu - (unsigned)(gg & 0xffffffffull);
                 const int y = (int)(idx / (unsigned)src.W), x = (int)(idx % (unsigned)src.W);
-                const int xr = min(x + 1, src.W - 1), xl = max(x - 1, 0), yd = min(y + 1, src.H - 1), yu = max(y - 1, 0);
-                // (all five samples are fetched before the first is looked at: one round trip, not three)
-                const float val = heat_at(src, b, k, y, x);
-                const float hr = heat_at(src, b, k, y, xr), hl = heat_at(src, b, k, y, xl), hd = heat_at(src, b, k, yd, x), hu = heat_at(src, b, k, yu, x);
-                if (val > 0.f) {
+                const int sx = lane == 1 ? min(x + 1, src.W - 1) : lane == 2 ? max(x - 1, 0) : x;
+                const int sy = lane == 3 ? min(y + 1, src.H - 1) : lane == 4 ? max(y - 1, 0) : y;
+                float hs1[1] = {0.f};
+                if (lane < 5) {
+                    const int ys[1] = {sy}, xs[1] = {sx};
+                    heat_otf<1>(src, b, k, ys, xs, hs1);
+                }
+                const float hs = hs1[0];
+                const float val = __shfl(hs, 0), hr = __shfl(hs, 1), hl = __shfl(hs, 2), hd = __shfl(hs, 3), hu = __shfl(hs, 4);
+                if (lane == 0 && val > 0.f) {
+                    float *j = joints + (((size_t)b * M + p) * src.K + k) * (3 + E);
                     double fx = (double)x + 0.5, fy = (double)y + 0.5;
                     if (hr > hl) fx += 0.25; else fx -= 0.25;
                     if (hd > hu) fy += 0.25; else fy -= 0.25;
@@ -278,7 +328,7 @@ __global__ __launch_bounds__(256, REFINE_WPS) void refine_bb_kernel(const Decode
 hipError_t launch_refine_bb(const DecodeSrc &src, int M, float *joints, const float *ws_prev, const int32_t *ws_jobs, const float *cellmax,
                             const float *tagb, const unsigned short *supmax, const unsigned *suptag, hipStream_t s)
 {
-    hipLaunchKernelGGL(refine_bb_kernel, dim3(2048), dim3(256), 0, s, src, M, ws_jobs, ws_prev, reinterpret_cast<const unsigned short *>(cellmax),
+    hipLaunchKernelGGL(refine_bb_kernel, dim3(2048 * (256 / RT)), dim3(RT), 0, s, src, M, ws_jobs, ws_prev, reinterpret_cast<const unsigned short *>(cellmax),
                        reinterpret_cast<const unsigned *>(tagb), supmax, suptag, joints);
     return hipGetLastError();
 }
