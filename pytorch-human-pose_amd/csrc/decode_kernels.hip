@@ -1156,8 +1156,11 @@ __global__ __launch_bounds__(256) void adjust_scores_kernel(const DecodeSrc src,
     __syncthreads();
     for (int p = tid; p < M; p += 256)
         scores[(size_t)b * M + p] = p < P ? __fdiv_rn(np_sum_f32(sl + (size_t)p * K, K, 1), (float)K) : 0.f;
-    if (!refine || tid >= P) return;
-    {
+    if (!refine) return;
+    __shared__ int qcnt[8], qbase[8];
+    __shared__ unsigned char pok[HH_MAX_PEOPLE];  // the person has a mean tag (at least one detected joint)
+    if (tid < 8) qcnt[tid] = 0;
+    if (tid < P) {
         const int p = tid;
         const float *Sp = sl + (size_t)p * K;
         float *mine = tl + (size_t)p * K * E;  // compacted in place, in joint order (the write index never passes the read index)
@@ -1169,17 +1172,27 @@ __global__ __launch_bounds__(256) void adjust_scores_kernel(const DecodeSrc src,
             }
         float *out = ws_prev + ((size_t)b * M + p) * (HH_MAX_EMB + 1);
         out[HH_MAX_EMB] = (float)nt;
-        if (!nt) return;
-        np_mean_rows(mine, nt, E, out);
-        // work lists for the arg-max kernel: every joint of this person still missing, in 8 queues by map ((b*K + k) % 8).
-        // A queue is served by the workgroups of ONE XCD, so the several people that miss the same joint of an image scan that
-        // map's cell maxima / tag bounds out of the same L2 instead of fetching them once per XCD.
-        const int cap = gridDim.x * M * K;  // queue capacity = every (b, p, k)
-        for (int k = 0; k < K; ++k)
-            if (Sp[k] == 0.f) {
-                const int qx = (b * K + k) & 7;
-                ws_jobs[8 + qx * cap + atomicAdd(ws_jobs + qx, 1)] = (b << 16) | (p << 8) | k;
-            }
+        pok[p] = nt != 0;
+        if (nt) np_mean_rows(mine, nt, E, out);
+    }
+    __syncthreads();
+    // work lists for the arg-max kernel: every joint still missing of a person that has a mean tag, in 8 queues by map ((b*K + k) % 8).
+    // A queue is served by the workgroups of ONE XCD, so the several people that miss the same joint of an image scan that map's
+    // bounds out of the same L2 instead of fetching them once per XCD.  One global atomic per queue and image: the jobs take their
+    // places inside the image's share by LDS atomics (round 3: one returning global atomic per job, issued joint by joint by the
+    // person's thread -- fifteen dependent round trips, most of this kernel's time).
+    const int cap = gridDim.x * M * K;  // queue capacity = every (b, p, k)
+    __shared__ unsigned short jslot[HH_MAX_PEOPLE * 64];  // a job's place inside the image's share of its queue
+    for (int i = tid; i < P * K; i += 256) {
+        const int p = i / K;
+        if (sl[i] == 0.f && pok[p]) jslot[i] = (unsigned short)atomicAdd(&qcnt[(b * K + i - p * K) & 7], 1);
+    }
+    __syncthreads();
+    if (tid < 8) qbase[tid] = qcnt[tid] ? atomicAdd(ws_jobs + tid, qcnt[tid]) : 0;
+    __syncthreads();
+    for (int i = tid; i < P * K; i += 256) {
+        const int p = i / K, kk = i - p * K, qx = (b * K + kk) & 7;
+        if (sl[i] == 0.f && pok[p]) ws_jobs[8 + qx * cap + qbase[qx] + jslot[i]] = (b << 16) | (p << 8) | kk;
     }
 }
 
