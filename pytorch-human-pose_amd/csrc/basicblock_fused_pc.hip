@@ -160,11 +160,24 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int nloc = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     auto band = [&](int i) { return ((p.ntiles & 7) == 0 && (gridDim.x & 7) == 0) ? (i & 7) * (p.ntiles >> 3) + (i >> 3) : i; };
+    // Rows.  Plain layout: a tile belongs to one image (b, first output row oy0).  TALL layout (round 4, p.VH = H + 2): the batch is
+    // one image of B * (H + 2) rows -- two rows of zeros between consecutive images, what both 3x3 convolutions see as padding -- and
+    // the tiles run through it without regard to the image borders, so only the very last tile row is partly empty (128 rows = 9.14
+    // tiles of 14: a tenth of the plain layout's tiles were the 2-row remainders of the images).  A tile then touches at most two
+    // images: b is the image of its first output row, oy0 that row's index inside it, and a row index y = oy0 + d that reaches VH
+    // belongs to image b + 1, row y - VH (rowmap); rows H, H + 1 are the gap.  Plain layout: VH = 2^30, never reached.
     struct Geom { int b, oy0, ox0; };
     auto geom = [&](int k) {  // k-th tile of this workgroup
         const int tb = band((int)blockIdx.x + k * (int)gridDim.x);
-        const int b = tb / tiles_per_img, tt = tb % tiles_per_img;
-        return Geom{b, (tt / p.tiles_x) * TH, (tt % p.tiles_x) * TW};
+        const int u = tb / tiles_per_img, tt = tb % tiles_per_img;
+        const int oy = (tt / p.tiles_x) * TH, bq = oy / p.VH;
+        return Geom{u + bq, oy - bq * p.VH, (tt % p.tiles_x) * TW};
+    };
+    // row y = oy0 + d of the tile of image b -> flat row (image * H + row) of the tensor, or -1 outside every image
+    auto rowmap = [&](int b, int y) {
+        const bool wrap = y >= p.VH;
+        const int ya = wrap ? y - p.VH : y, bb = wrap ? b + 1 : b;
+        return (((unsigned)ya < (unsigned)p.H) & (bb < p.B)) ? bb * p.H + ya : -1;
     };
 
     // ---- patch prefetch: global -> registers (issued early in an iteration) -> LDS (late in the same iteration).
@@ -178,21 +191,25 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
     const int pu_key = (pu_cu ^ (pu_px >> 2)) & 3;                 // part ^ x key; the row key is XORed in per round
     const int pu_lbase = (pu_row * PRS + pu_px) * 64;
     const int pf_rowstep = 3 * p.W * p.in_cs * 2;
+    const int pf_gapstep = (p.VH - p.H) * p.W * p.in_cs * 2;  // (tall layout) what a flat row index skips at an image border
     unsigned pf_vbase = 0;  // byte offset of this thread's round-0 unit
     int pf_y = 0;           // image row of that unit
-    bool pf_xok = false;
+    bool pf_xok = false, pf_next = false;
     auto pf_setup = [&](int k) {
         const bool on = k < nloc;
         const Geom g = geom(on ? k : 0);
         const int ix = g.ox0 - 2 + pu_px;
         pf_y = g.oy0 - 2 + pu_row;
         pf_xok = on & pu_act & ((unsigned)ix < (unsigned)p.W);
+        pf_next = g.b + 1 < p.B;
         pf_vbase = (unsigned)(((g.b * p.H + pf_y) * p.W + ix) * p.in_cs * 2 + (pu_cu & 3) * 16);
     };
     auto pf_load = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const bool ok = pf_xok & ((unsigned)(pf_y + 3 * i) < (unsigned)p.H);
-        const unsigned voff = ok ? pf_vbase + (unsigned)(i * pf_rowstep) : OOB;  // outside the image: zero = conv1's padding
+        const int yy = pf_y + 3 * i;
+        const bool wrap = yy >= p.VH;  // (tall layout) the row belongs to the next image
+        const bool ok = pf_xok & ((unsigned)(wrap ? yy - p.VH : yy) < (unsigned)p.H) & (!wrap | pf_next);
+        const unsigned voff = ok ? pf_vbase + (unsigned)(i * pf_rowstep) - (wrap ? (unsigned)pf_gapstep : 0u) : OOB;  // outside the image: zero = conv1's padding
 #ifdef BBPC_NOLOAD  // timing experiment: no patch traffic (results are wrong)
         preg[i] = u32x4{voff, 0u, 0u, 0u};
 #else
@@ -275,8 +292,8 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
             };
             auto edge_out = [&]() {
                 if constexpr (!EDGE) return;
-                const int gy = g.oy0 - 1 + mrow, gxe = g.ox0 - 1 + mcol;
-                const bool outside = ((unsigned)gy >= (unsigned)p.H) | ((unsigned)gxe >= (unsigned)p.W);
+                const int gxe = g.ox0 - 1 + mcol;
+                const bool outside = (rowmap(g.b, g.oy0 - 1 + mrow) < 0) | ((unsigned)gxe >= (unsigned)p.W);
                 u32x4 o[2];
                 pack_rows16(acc[RP + (EDGE ? 0 : -1)], o);
 #pragma unroll
@@ -316,10 +333,10 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
             const bool ragged = g.ox0 + TW - 1 > p.W;  // wave-uniform: some main column ox0 - 1 + r is >= W
 #pragma unroll
             for (int j = 0; j < RP; ++j) {
-                const int m = 4 * wj + j, gy = g.oy0 - 1 + m;
+                const int m = 4 * wj + j;
                 u32x4 o[2];
                 pack_rows16(acc[j], o);
-                if ((unsigned)gy >= (unsigned)p.H) o[0] = o[1] = u32x4{0u, 0u, 0u, 0u};
+                if (rowmap(g.b, g.oy0 - 1 + m) < 0) o[0] = o[1] = u32x4{0u, 0u, 0u, 0u};
                 else if (ragged) {
                     const bool outside = g.ox0 - 1 + r >= p.W;
                     o[0] = outside ? u32x4{0u, 0u, 0u, 0u} : o[0];
@@ -361,14 +378,14 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
                 const int ox = g.ox0 + r;
 #pragma unroll
                 for (int j = 0; j < RC; ++j) {
-                    const int oy = g.oy0 + c0 + j;
+                    const int fr = rowmap(g.b, g.oy0 + c0 + j);
                     u32x4 o[2];
                     pack_rows16(acc[j], o);
-                    const bool ok = (oy < p.H) & (ox < p.W);
+                    const bool ok = (fr >= 0) & (ox < p.W);
 #ifdef BBPC_NOSTORE
-                    const unsigned voff = (ok && o[0][0] == 0x12345678u) ? (unsigned)(((g.b * p.H + oy) * p.W + ox) * p.out_cs * 2 + 16 * h) : OOB;
+                    const unsigned voff = (ok && o[0][0] == 0x12345678u) ? (unsigned)((fr * p.W + ox) * p.out_cs * 2 + 16 * h) : OOB;
 #else
-                    const unsigned voff = ok ? (unsigned)(((g.b * p.H + oy) * p.W + ox) * p.out_cs * 2 + 16 * h) : OOB;
+                    const unsigned voff = ok ? (unsigned)((fr * p.W + ox) * p.out_cs * 2 + 16 * h) : OOB;
 #endif
                     __builtin_amdgcn_raw_buffer_store_b128(o[0], rs_out, (int)voff, 0, BBPC_STORE_AUX);
                     __builtin_amdgcn_raw_buffer_store_b128(o[1], rs_out, (int)voff, 32, BBPC_STORE_AUX);
@@ -388,9 +405,9 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
                     const int ox = g.ox0 + r;
 #pragma unroll
                     for (int j = 0; j < RC; ++j) {
-                        const int oy = g.oy0 + c0 + j;
-                        const bool ok = (oy < p.H) & (ox < p.W);
-                        const unsigned voff = ok ? (unsigned)(((g.b * p.H + oy) * p.W + ox) * p.in_cs * 2 + 16 * h) : OOB;
+                        const int fr = rowmap(g.b, g.oy0 + c0 + j);
+                        const bool ok = (fr >= 0) & (ox < p.W);
+                        const unsigned voff = ok ? (unsigned)((fr * p.W + ox) * p.in_cs * 2 + 16 * h) : OOB;
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
 #ifdef BBPC_NORES
@@ -494,6 +511,15 @@ hipError_t bbpc_launch(BBParams p, int num_cus, hipStream_t s)
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    p.VH = 1 << 30;
+    if (p.tall != 0) {
+        // the batch as one tall image (see the kernel): fewer tiles whenever H is not a multiple of the tile height.  The tile rows are
+        // rounded up until the tile count is a multiple of 8 (the XCD-contiguous tile order needs that; the extra tiles lie behind
+        // the last image and move nothing)
+        int ty = (p.B * (p.H + 2) - 2 + TH - 1) / TH;
+        while ((ty * p.tiles_x) & 7) ++ty;
+        if (ty * p.tiles_x < p.ntiles || p.tall > 1) { p.tiles_y = ty; p.ntiles = ty * p.tiles_x; p.VH = p.H + 2; }
+    }
     if (!bbpc_supported(p)) return hipErrorInvalidValue;
     const int grid = p.ntiles < num_cus ? p.ntiles : num_cus;
     HH_LAUNCH(bbpc_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, s, p);

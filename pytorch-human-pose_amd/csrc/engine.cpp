@@ -32,6 +32,7 @@ PlanSwitches PlanSwitches::from_env()
     s.poison_lds = on("HH_POISON_LDS");
     s.no_head_fold = on("HH_NO_HEAD_FOLD");
     s.no_conv_db = on("HH_NO_CONV_DB");
+    s.bb_tall = on("HH_NO_BB_TALL") ? 0 : is("HH_BB_TALL", "always") ? 2 : 1;
     if (const char *fc = getenv("HH_FAT_CUS")) { s.fat_cus = s.fat_cus64 = atoi(fc); if (const char *c2 = strchr(fc, ',')) s.fat_cus64 = atoi(c2 + 1); }
     if (const char *sk = getenv("HH_DEBUG_SKIP")) {
         static const struct { const char *name; unsigned bit; } cats[] = {{"s2big", SK_S2BIG}, {"s2", SK_S2}, {"upadd", SK_UPADD}, {"c1x1", SK_C1X1},
@@ -1132,6 +1133,7 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             p.in = ti.ptr; p.in_cs = ti.C; p.out = to.ptr; p.out_cs = to.C;
             p.w1 = l1.d_w; p.w2 = l2.d_w; p.b1 = l1.d_bias; p.b2 = l2.d_bias;
             p.B = B; p.H = H >> ti.shift; p.W = W >> ti.shift;
+            p.tall = sw.bb_tall;
             ProfRecord *pr = nullptr;
             if (prof_enabled) {
                 if (prof_used == prof.size()) {

@@ -144,6 +144,8 @@ struct PlanSwitches {
     // lanes find free CUs while either runs: forward 4.48 -> 4.39 ms, +1.5-2 % img/s (three alternations, profiles/r03_ab.md).
     // HH_FAT_CUS=n[,m] sets them (256 = one per CU, the round-2 plan); a quarter of the chip for the 64-channel block loses 6 %.
     int fat_cus = 0, fat_cus64 = 0;
+    int bb_tall = 1;               // the fused 32-channel block tiles the batch as one tall image when that needs fewer tiles (round 4);
+                                   // HH_NO_BB_TALL=1: per-image tiles (round 3), HH_BB_TALL=always: also where it needs more
     bool no_conv_db = false;       // HH_NO_CONV_DB=1: the 128- / 256-channel 3x3 convs on the single-buffer KC = 32 instantiations (round 2)
     bool no_head_fold = false;     // HH_NO_HEAD_FOLD=1: init_heatmaps_head writes its output into the concat buffer, the transposed conv reads it
     bool poison_lds = false;       // HH_POISON_LDS=1 (tests): every CU's LDS filled with NaN patterns in front of every launch

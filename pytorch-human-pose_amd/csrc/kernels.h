@@ -151,6 +151,8 @@ struct BBParams {
     const float *b1, *b2;            // [32]
     int B, H, W;
     int tiles_x, tiles_y, ntiles;    // filled by bb_fused_launch
+    int tall;                        // bbpc_launch: 1 = lay the batch out as one tall image when that needs fewer tiles (2: always), 0 = never
+    int VH;                          // filled by bbpc_launch: rows per image in the tall layout (H + 2), or 2^30
     bf16_raw *trash;                 // filled by bb_fused_launch: dummy line for the stores of lanes outside the image
     unsigned long long *stamps;      // diagnostic build (-DHH_STAMP) only
     unsigned long long *clk;         // optional {min start, max end} of the launch in wall_clock64() ticks

@@ -188,7 +188,10 @@ def test_schedule_and_fusion_switches(pkg, net_golden):
     x = torch.from_numpy(pkg.synth.synth_images(2, 128, 128, 1)).to(DEV)
     base, _ = _net(pkg, 32, 1)
     ref = [t.clone() for t in base.forward_raw(x)]
-    for env, exact in ((("HH_FULL_JOIN", "1"), True), (("HH_NO_FUSION_MERGE", "1"), False), (("HH_NO_JUNC_PAIR", "1"), True), (("HH_NO_CONV_DB", "1"), False)):
+    # (round 4) the fused 32-channel block tiles the batch as ONE tall image, two zero rows between the images (HH_BB_TALL=always: here too,
+    # where it needs more tiles than the per-image layout and is not chosen; HH_NO_BB_TALL=1: never): other tiles, the same sums
+    for env, exact in ((("HH_FULL_JOIN", "1"), True), (("HH_NO_FUSION_MERGE", "1"), False), (("HH_NO_JUNC_PAIR", "1"), True), (("HH_NO_CONV_DB", "1"), False),
+                       (("HH_BB_TALL", "always"), True), (("HH_NO_BB_TALL", "1"), True)):
         os.environ[env[0]] = env[1]
         try:
             net, _ = _net(pkg, 32, 1)
@@ -203,6 +206,17 @@ def test_schedule_and_fusion_switches(pkg, net_golden):
         else:
             for a, b in zip(got, ref):
                 assert (a - b).abs().max().item() <= 4e-2 * b.abs().max().item() and (a - b).pow(2).mean().sqrt().item() <= 2e-2 * b.pow(2).mean().sqrt().item()
+    # the tall layout where the default plan picks it (4 images of 512 x 512: 152 tiles of the 128-row maps instead of 160, 304 of the
+    # 256-row maps of the deconv head instead of 304 + ...) and on a ragged shape, against the per-image layout: bit for bit
+    for shape in ((4, 512, 512), (5, 352, 416)):
+        xs = torch.from_numpy(pkg.synth.synth_images(*shape, 9)).to(DEV)
+        tall = [t.clone() for t in base.forward_raw(xs)]
+        os.environ["HH_NO_BB_TALL"] = "1"
+        try:
+            plain, _ = _net(pkg, 32, 1)
+        finally:
+            del os.environ["HH_NO_BB_TALL"]
+        assert all(torch.equal(a, b) for a, b in zip(plain.forward_raw(xs), tall)), shape
 
 
 def test_forward_reads_no_unwritten_workspace(pkg):
