@@ -163,7 +163,7 @@ for n in set(fetch) | set(write):
         traffic["bbpc_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=32, producer/consumer waves)"] = round(total, -5)
     elif n.startswith("bb64_fused_kernel"):
         traffic["bb64_fused_kernel (conv3x3+BN+ReLU+conv3x3+BN+residual+ReLU, C=64)"] = round(total, -5)
-DECODE = ("stage_average", "nms_classify", "nms_tile_topk", "fallback_top1", "topk_merge", "match_kernel", "adjust_scores", "refine_", "tag_bounds")
+DECODE = ("stage_average", "nms_classify", "nms_tile_topk", "peaks_region", "fallback_top1", "topk_merge", "match_kernel", "adjust_scores", "refine_", "tag_bounds")
 traffic.update(fp8_traffic)
 traffic["hh_decode (all kernels of one call)"] = round(sum(2 * fetch.get(n, 0.0) + write.get(n, 0.0) for n in set(fetch) | set(write)
                                                            if n.startswith(DECODE)), -5)
