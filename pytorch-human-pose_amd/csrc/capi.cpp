@@ -701,10 +701,6 @@ extern "C" int hh_debug_bb_compare(int B, int H, int W, int iters, float *max_di
     HH_CHECK_HIP(conv_init());
     HH_CHECK_HIP(bb_fused_init());
     HH_CHECK_HIP(bbpc_init());
-    HH_CHECK_HIP(bbsw_init());
-    // HH_BB_CMP=sw: the second kernel is the single-wave form and the FIRST the producer / consumer form (they must agree bit for bit)
-    const char *cmp_env = getenv("HH_BB_CMP");
-    const bool cmp_sw = cmp_env && !strcmp(cmp_env, "sw");
     const size_t n = (size_t)B * H * W * 32;
     std::vector<bf16_raw> h_in(n), h_w(2 * 9 * 32 * 32), h_o1(n), h_o2(n);
     std::vector<float> h_b(64);
@@ -744,10 +740,7 @@ extern "C" int hh_debug_bb_compare(int B, int H, int W, int iters, float *max_di
     float ms[2] = {0, 0};
     for (int v = 0; v < 2; ++v) {
         p.out = v ? d_o2 : d_o1;
-        auto go = [&]() {
-            if (cmp_sw) return v ? bbsw_launch(p, prop.multiProcessorCount, st) : bbpc_launch(p, prop.multiProcessorCount, st);
-            return v ? bbpc_launch(p, prop.multiProcessorCount, st) : bb_fused_launch(p, prop.multiProcessorCount, st);
-        };
+        auto go = [&]() { return v ? bbpc_launch(p, prop.multiProcessorCount, st) : bb_fused_launch(p, prop.multiProcessorCount, st); };
         for (int i = 0; i < 3; ++i) HH_CHECK_HIP(go());
         HH_CHECK_HIP(hipEventRecord(e0, st));
         for (int i = 0; i < iters; ++i) HH_CHECK_HIP(go());

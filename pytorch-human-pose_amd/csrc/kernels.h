@@ -165,10 +165,6 @@ hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s);
 hipError_t bbpc_init();
 bool bbpc_supported(const BBParams &p);
 hipError_t bbpc_launch(BBParams p, int num_cus, hipStream_t s);
-// single-wave form (basicblock_fused_sw.hip, experimental): one wavefront per SIMD runs both convolutions of its row band; same results
-hipError_t bbsw_init();
-bool bbsw_supported(const BBParams &p);
-hipError_t bbsw_launch(BBParams p, int num_cus, hipStream_t s);
 // the same block for the 64-channel branch (basicblock_fused_c64.hip): weights packed KS=3,S=1,KC=32,NT=2 ([chunk][tap][4][64][8])
 #define HH_CFG_BB64_FUSED 103
 hipError_t bb64_fused_init();
