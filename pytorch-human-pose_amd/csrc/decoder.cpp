@@ -65,6 +65,7 @@ int hh_decoder::reserve(int B, int H, int W, int E)
     if (alloc(((size_t)nB * M * K * 8 + 8) * 4, (void **)&ws_jobs)) return 1;  // 8 counters + 8 job queues (one per XCD)
     if (alloc((size_t)nB * 4, (void **)&flags)) return 1;
     HH_CHECK_HIP(hipMemset(flags, 0, (size_t)nB * 4));
+    HH_CHECK_HIP(hipDeviceSynchronize());  // (a null-stream memset is not ordered in front of launches on a non-blocking stream)
     const int nsup = std::max(std::max(nsup_of(nH, nW), nsup_of(H, W)), rsup);
     if (alloc((size_t)nB * K * nsup * 2, (void **)&supmax)) return 1;
     if (alloc((size_t)nB * K * nsup * nE * 4, (void **)&suptag)) return 1;

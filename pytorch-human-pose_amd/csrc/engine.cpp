@@ -837,6 +837,11 @@ int hh_net::reserve(int B, int H, int W)
             t.is16 = dtype == 2 && d.b16;
             if (alloc((size_t)nB * (nH >> d.shift) * (nW >> d.shift) * d.C * (t.is16 ? 2 : elem()), (void **)&t.copy)) return 1;
         }
+    // The memsets above (zero-initialised tensors, the constant-one channel, poison patterns) run on the NULL stream and are
+    // asynchronous with respect to the host; the forward that follows is enqueued on the caller's stream, which for torch is a
+    // non-blocking one: without this wait its first launches could read the workspace before it is initialised (round 4 found
+    // that race in the decoder's work counters; it may be what stopped one forward test once in round 2).  Once per shape growth.
+    HH_CHECK_HIP(hipDeviceSynchronize());
     ws_ready = true;
     rB = nB; rH = nH; rW = nW;
     return 0;
