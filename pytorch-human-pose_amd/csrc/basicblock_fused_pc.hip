@@ -108,8 +108,9 @@ constexpr int RDC = 4, NFBC = RDC + 1;  // consumer (more registers to spare)
 constexpr int RP = MH / 4;                  // mid rows per producer wave
 static_assert(MH % 4 == 0 && 2 * MH == 32, "4 producer bands; the two extra mid columns make exactly one 32-pixel column tile");
 constexpr int OFF_MID = 2 * PATCH_BYTES, OFF_BIAS = OFF_MID + 2 * MID_BYTES;
-constexpr int LDS_BYTES = OFF_BIAS + 256;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+constexpr int OFF_FINW = OFF_BIAS + 256, OFF_FINB = OFF_FINW + 2048;  // (FIN) the 1x1 head's B fragments [2][2][32][8] bf16 and its bias [32]
+constexpr int LDS_BYTES = OFF_BIAS + 256, LDS_BYTES_FIN = OFF_FINB + 128;
+static_assert(LDS_BYTES_FIN <= 160 * 1024, "LDS");
 }  // namespace
 
 #ifdef HH_STAMP  // phase stamps of workgroup 0, iteration 2 (steady state): 8 slots per wave
@@ -118,7 +119,13 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 #define PSTAMP(i)
 #endif
 
-__global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
+// FIN: the block is the last one of DeconvHeatmapsHead and the head's final 1x1 convolution (32 -> K channels with bias, fp32 NCHW
+// result; higher_hrnet.py:38-44) runs in the consumer's epilogue: the packed bf16 rows of the block output are, as they stand, the A
+// operand (32 pixels x 16 channels per k half) of two more MFMAs against the head's weights (B: 16 channels x 32 couts, K real), so
+// the block output is never stored (-134 MB written, -134 MB read at B = 32 @ 512^2) and the head's launch disappears.  The result
+// tile is D[pixel 8q + 4h + t][cout r] in d[4q + t]: a lane stores four float4 per row, 16 consecutive bytes of one channel plane.
+template <bool FIN>
+__device__ __forceinline__ void bbpc_body(const BBParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -139,7 +146,8 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
 
     const size_t in_bytes = (((size_t)p.B * p.H * p.W - 1) * p.in_cs + 32) * 2, out_bytes = (((size_t)p.B * p.H * p.W - 1) * p.out_cs + 32) * 2;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_raw *>(p.in), 0, (int)in_bytes, 0x00020000);
-    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
+    const auto rs_out = FIN ? __builtin_amdgcn_make_buffer_rsrc(p.fin_out, 0, (int)((size_t)p.B * p.fin_K * p.H * p.W * 4), 0x00020000)
+                            : __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;  // a byte offset past every tensor here: the load returns 0, the store is dropped
 
     // ---- this wave's weight fragments (A operand: 32 couts x 16 cin per (tap, k half)), resident in registers
@@ -154,6 +162,10 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
     if (tid < 32) {
         reinterpret_cast<float *>(smem + OFF_BIAS)[tid] = p.b1[tid];
         reinterpret_cast<float *>(smem + OFF_BIAS)[32 + tid] = p.b2[tid];
+    }
+    if constexpr (FIN) {
+        if (tid >= 64 && tid < 192) reinterpret_cast<u32x4 *>(smem + OFF_FINW)[tid - 64] = reinterpret_cast<const u32x4 *>(p.fin_w)[tid - 64];
+        if (tid >= 192 && tid < 224) reinterpret_cast<float *>(smem + OFF_FINB)[tid - 192] = p.fin_b[tid - 192];
     }
 
     // ---- tiles of this workgroup, XCD-aware order as in basicblock_fused.hip
@@ -376,6 +388,41 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
             auto finish = [&](int k) {
                 const Geom g = geom(k);
                 const int ox = g.ox0 + r;
+                if constexpr (FIN) {
+                    const u32x4 fw0 = *reinterpret_cast<const u32x4 *>(smem + OFF_FINW + (h * 32 + r) * 16);
+                    const u32x4 fw1 = *reinterpret_cast<const u32x4 *>(smem + OFF_FINW + ((2 + h) * 32 + r) * 16);
+                    const float fb = reinterpret_cast<const float *>(smem + OFF_FINB)[r];
+                    // this lane's channel plane r, pixels ox0 + 4h .. (+ 8q per store); lanes of the padding couts store nowhere
+                    const bool lane_ok = r < p.fin_K;
+                    const unsigned lane_off = (unsigned)((r * p.H * p.W + g.ox0 + 4 * h) * 4);
+#pragma unroll
+                    for (int j = 0; j < RC; ++j) {
+                        const int y = g.oy0 + c0 + j;
+                        const bool wrap = y >= p.VH;
+                        const int ya = wrap ? y - p.VH : y, bb = wrap ? g.b + 1 : g.b;
+                        const bool row_ok = ((unsigned)ya < (unsigned)p.H) & (bb < p.B);
+                        u32x4 o[2];
+                        pack_rows16(acc[j], o);
+                        f32x16 d;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) d[i] = fb;
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o[0]), __builtin_bit_cast(bf16x8, fw0), d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o[1]), __builtin_bit_cast(bf16x8, fw1), d, 0, 0, 0);
+                        const unsigned row_off = (unsigned)(((bb * p.fin_K * p.H + ya) * p.W) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool ok = lane_ok & row_ok & (g.ox0 + 8 * q + 4 * h < p.W);  // (W % 4 == 0: the four pixels are inside together)
+#ifdef BBPC_NOSTORE
+                            const unsigned voff = (ok && d[0] == 1.2345f) ? row_off + lane_off : OOB;
+#else
+                            const unsigned voff = ok ? row_off + lane_off : OOB;
+#endif
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(d[4 * q]), __float_as_uint(d[4 * q + 1]), __float_as_uint(d[4 * q + 2]),
+                                                                         __float_as_uint(d[4 * q + 3])}, rs_out, (int)voff, 32 * q, BBPC_STORE_AUX);
+                        }
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int j = 0; j < RC; ++j) {
                     const int fr = rowmap(g.b, g.oy0 + c0 + j);
@@ -495,15 +542,26 @@ __global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p)
 #endif
 }
 
+__global__ __launch_bounds__(NTHR, 1) void bbpc_kernel(const BBParams p) { bbpc_body<false>(p); }
+__global__ __launch_bounds__(NTHR, 1) void bbpc_final_kernel(const BBParams p) { bbpc_body<true>(p); }
+
 hipError_t bbpc_init()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(bbpc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bbpc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(bbpc_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FIN);
 }
 
 // 32-bit buffer offsets: both tensors must stay below 2 GB (the engine falls back to the tile form otherwise)
 bool bbpc_supported(const BBParams &p)
 {
     return (size_t)p.B * p.H * p.W * (size_t)(p.in_cs > p.out_cs ? p.in_cs : p.out_cs) * 2 < 0x7fffffffull;
+}
+
+// the block with the head's 1x1 convolution in its epilogue (p.fin_*): fp32 NCHW result below 2 GB, widths in whole float4s
+bool bbpc_final_supported(const BBParams &p)
+{
+    return bbpc_supported(p) && p.fin_K >= 1 && p.fin_K <= 32 && p.W % 4 == 0 && (size_t)p.B * p.fin_K * p.H * p.W * 4 < 0x7fffffffull;
 }
 
 hipError_t bbpc_launch(BBParams p, int num_cus, hipStream_t s)
@@ -520,8 +578,13 @@ hipError_t bbpc_launch(BBParams p, int num_cus, hipStream_t s)
         while ((ty * p.tiles_x) & 7) ++ty;
         if (ty * p.tiles_x < p.ntiles || p.tall > 1) { p.tiles_y = ty; p.ntiles = ty * p.tiles_x; p.VH = p.H + 2; }
     }
-    if (!bbpc_supported(p)) return hipErrorInvalidValue;
     const int grid = p.ntiles < num_cus ? p.ntiles : num_cus;
-    HH_LAUNCH(bbpc_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, s, p);
+    if (p.fin_out) {
+        if (!bbpc_final_supported(p)) return hipErrorInvalidValue;
+        HH_LAUNCH(bbpc_final_kernel, dim3(grid), dim3(NTHR), LDS_BYTES_FIN, s, p);
+    } else {
+        if (!bbpc_supported(p)) return hipErrorInvalidValue;
+        HH_LAUNCH(bbpc_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, s, p);
+    }
     return hipGetLastError();
 }

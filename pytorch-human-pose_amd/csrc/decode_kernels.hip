@@ -602,19 +602,40 @@ __device__ __forceinline__ void tag_bounds_part(const DecodeSrc &src, float *__r
         const int qc = min(qx, wq - 1), xa = max(qc - 1, 0), xb = min(qc + 1, wq - 1);
         for (int e = 0; e < E; ++e) {
             const float *tq = src.tags_q[e] + (size_t)b * src.tags_bs[e] + (size_t)k * hq * wq;
-            float rlo[TBR + 2], rhi[TBR + 2];
+            // Round 4: the hull of the cell's 16 PIXEL tags themselves (the x4 bilinear of the 3x3 taps, in tag_at()'s / the refine
+            // evaluation's own expressions: three tap rows along x at the four sub-columns, then along y), not of the nine taps: a
+            // pixel weighs its outer taps with at most 0.375, so the hull is much narrower where the tags change (blob rims), and
+            // the refine scans open and evaluate correspondingly fewer cells.  The work rides beside the matcher on an idle chip.
+            constexpr int TO4[4] = {0, 0, 1, 1};
+            constexpr float TW4[4] = {0.625f, 0.875f, 0.125f, 0.375f};
+            float hx[TBR + 2][4];
 #pragma unroll
             for (int r = 0; r < TBR + 2; ++r) {
                 const float *row = tq + (size_t)min(max(qy0 - 1 + r, 0), hq - 1) * wq;
-                const float t0 = row[xa], t1 = row[qc], t2 = row[xb];
-                rlo[r] = fminf(fminf(t0, t1), t2); rhi[r] = fmaxf(fmaxf(t0, t1), t2);
+                const float t[3] = {row[xa], row[qc], row[xb]};
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    const bool first = qc == 0 && jx < 2;  // source position below 0: torch reads sample 0 with weight 1
+                    const float w0 = first ? 0.f : 1.f - TW4[jx], w1 = first ? 1.f : TW4[jx];
+                    hx[r][jx] = __builtin_fmaf(t[TO4[jx]], w0, t[TO4[jx] + 1] * w1);
+                }
             }
             float slo = INFINITY, shi = -INFINITY;  // the hull of this thread's cells, as stored
 #pragma unroll
             for (int r = 0; r < TBR; ++r) {
                 if (qy0 + r >= hq) break;
-                const float lo = fminf(fminf(rlo[r], rlo[r + 1]), rlo[r + 2]), hi = fmaxf(fmaxf(rhi[r], rhi[r + 1]), rhi[r + 2]);
-                const float slack = 1e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-30f;  // >> 3 roundings of a convex combination
+                float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+                for (int jy = 0; jy < 4; ++jy) {
+                    const bool first = qy0 + r == 0 && jy < 2;
+                    const float w0 = first ? 0.f : 1.f - TW4[jy], w1 = first ? 1.f : TW4[jy];
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        const float tg = __builtin_fmaf(hx[r + TO4[jy]][jx], w0, hx[r + TO4[jy] + 1][jx] * w1);
+                        lo = fminf(lo, tg); hi = fmaxf(hi, tg);
+                    }
+                }
+                const float slack = 1e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-30f;  // (the values are the evaluation's own; the slack is belt and braces)
                 // stored as a bf16 pair in one dword (lo rounded DOWN, hi rounded UP: the bound only gets looser), which
                 // halves what the arg-max scans have to read per cell
                 const unsigned lh = (unsigned)bf16_floor(lo - slack) | ((unsigned)bf16_ceil(hi + slack) << 16);

@@ -154,6 +154,11 @@ struct BBParams {
     int tall;                        // bbpc_launch: 1 = lay the batch out as one tall image when that needs fewer tiles (2: always), 0 = never
     int VH;                          // filled by bbpc_launch: rows per image in the tall layout (H + 2), or 2^30
     bf16_raw *trash;                 // filled by bb_fused_launch: dummy line for the stores of lanes outside the image
+    // bbpc_launch only: the 1x1 head behind the block, run in its epilogue (fin_out != nullptr; `out` is then not written)
+    const bf16_raw *fin_w;           // [k half 2][lane half 2][32 couts][8 cin] bf16, couts >= fin_K zero
+    const float *fin_b;              // [32]
+    float *fin_out;                  // [B, fin_K, H, W] fp32
+    int fin_K;
     unsigned long long *stamps;      // diagnostic build (-DHH_STAMP) only
     unsigned long long *clk;         // optional {min start, max end} of the launch in wall_clock64() ticks
 };
@@ -164,6 +169,7 @@ hipError_t bb_fused_launch(BBParams p, int num_cus, hipStream_t s);
 // producer / consumer form of the same block (basicblock_fused_pc.hip): weights resident in registers, row-band fragment reuse
 hipError_t bbpc_init();
 bool bbpc_supported(const BBParams &p);
+bool bbpc_final_supported(const BBParams &p);
 hipError_t bbpc_launch(BBParams p, int num_cus, hipStream_t s);
 // the same block for the 64-channel branch (basicblock_fused_c64.hip): weights packed KS=3,S=1,KC=32,NT=2 ([chunk][tap][4][64][8])
 #define HH_CFG_BB64_FUSED 103
