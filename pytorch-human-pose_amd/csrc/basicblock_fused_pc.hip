@@ -388,41 +388,6 @@ __device__ __forceinline__ void bbpc_body(const BBParams &p)
             auto finish = [&](int k) {
                 const Geom g = geom(k);
                 const int ox = g.ox0 + r;
-                if constexpr (FIN) {
-                    const u32x4 fw0 = *reinterpret_cast<const u32x4 *>(smem + OFF_FINW + (h * 32 + r) * 16);
-                    const u32x4 fw1 = *reinterpret_cast<const u32x4 *>(smem + OFF_FINW + ((2 + h) * 32 + r) * 16);
-                    const float fb = reinterpret_cast<const float *>(smem + OFF_FINB)[r];
-                    // this lane's channel plane r, pixels ox0 + 4h .. (+ 8q per store); lanes of the padding couts store nowhere
-                    const bool lane_ok = r < p.fin_K;
-                    const unsigned lane_off = (unsigned)((r * p.H * p.W + g.ox0 + 4 * h) * 4);
-#pragma unroll
-                    for (int j = 0; j < RC; ++j) {
-                        const int y = g.oy0 + c0 + j;
-                        const bool wrap = y >= p.VH;
-                        const int ya = wrap ? y - p.VH : y, bb = wrap ? g.b + 1 : g.b;
-                        const bool row_ok = ((unsigned)ya < (unsigned)p.H) & (bb < p.B);
-                        u32x4 o[2];
-                        pack_rows16(acc[j], o);
-                        f32x16 d;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) d[i] = fb;
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o[0]), __builtin_bit_cast(bf16x8, fw0), d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o[1]), __builtin_bit_cast(bf16x8, fw1), d, 0, 0, 0);
-                        const unsigned row_off = (unsigned)(((bb * p.fin_K * p.H + ya) * p.W) * 4);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const bool ok = lane_ok & row_ok & (g.ox0 + 8 * q + 4 * h < p.W);  // (W % 4 == 0: the four pixels are inside together)
-#ifdef BBPC_NOSTORE
-                            const unsigned voff = (ok && d[0] == 1.2345f) ? row_off + lane_off : OOB;
-#else
-                            const unsigned voff = ok ? row_off + lane_off : OOB;
-#endif
-                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(d[4 * q]), __float_as_uint(d[4 * q + 1]), __float_as_uint(d[4 * q + 2]),
-                                                                         __float_as_uint(d[4 * q + 3])}, rs_out, (int)voff, 32 * q, BBPC_STORE_AUX);
-                        }
-                    }
-                    return;
-                }
 #pragma unroll
                 for (int j = 0; j < RC; ++j) {
                     const int fr = rowmap(g.b, g.oy0 + c0 + j);
@@ -465,7 +430,7 @@ __device__ __forceinline__ void bbpc_body(const BBParams &p)
                     }
                 }
                 static_for<NPL>(pf_load);  // the next patch: written to LDS late in the MFMA loop
-                if (it >= 2) finish(it - 2);
+                if constexpr (!FIN) { if (it >= 2) finish(it - 2); }
                 PSTAMP(1);
                 const int pnext = ((it + 1) & 1) * PATCH_BYTES;
                 if (it >= 1) {
@@ -518,6 +483,45 @@ __device__ __forceinline__ void bbpc_body(const BBParams &p)
                         });
                         __builtin_amdgcn_sched_group_barrier(0x8, nm, 0);
                     });
+                    if constexpr (FIN) {
+                        // the head: block output rows (ReLU, bf16: what the unfused head reads back) x head weights, then bias, then
+                        // out -- in THIS iteration, not carried over the barrier like the bf16 tile of the plain block: fp32 result
+                        // tiles cannot be packed to half their registers, and 64 of them beside the next tile's residual and patch
+                        // loads do not fit.  The fragment, residual and prefetch registers of the loop above are free here.
+                        // (asm reads: as plain loads these loop invariants are hoisted out of the tile loop and their 8 registers spill)
+                        u32x4 fw0 = lds_read_async<0>(lds0 + OFF_FINW + (h * 32 + r) * 16), fw1 = lds_read_async<1024>(lds0 + OFF_FINW + (h * 32 + r) * 16);
+                        const float fb = reinterpret_cast<const float *>(smem + OFF_FINB)[r];
+                        lds_wait<1>(fw0);
+                        lds_wait<0>(fw1);
+                        // this lane's channel plane r, pixels ox0 + 4h .. (+ 8q per store); lanes of the padding couts store nowhere
+                        const bool lane_ok = r < p.fin_K;
+                        const unsigned lane_off = (unsigned)((r * p.H * p.W + g.ox0 + 4 * h) * 4);
+#pragma unroll
+                        for (int j = 0; j < RC; ++j) {
+                            u32x4 o[2];
+                            pack_rows16(acc[j], o);
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // (an inline constant: no registers)
+                            f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o[0]), __builtin_bit_cast(bf16x8, fw0), zero, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o[1]), __builtin_bit_cast(bf16x8, fw1), d, 0, 0, 0);
+                            const int y = g.oy0 + c0 + j;
+                            const bool wrap = y >= p.VH;
+                            const int ya = wrap ? y - p.VH : y, bb = wrap ? g.b + 1 : g.b;
+                            const bool row_ok = ((unsigned)ya < (unsigned)p.H) & (bb < p.B);
+                            const unsigned row_off = (unsigned)(((bb * p.fin_K * p.H + ya) * p.W) * 4);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const bool ok = lane_ok & row_ok & (g.ox0 + 8 * q + 4 * h < p.W);  // (W % 4 == 0: the four pixels are inside together)
+#ifdef BBPC_NOSTORE
+                                const unsigned voff = (ok && d[0] == 1.2345f) ? row_off + lane_off : OOB;
+#else
+                                const unsigned voff = ok ? row_off + lane_off : OOB;
+#endif
+                                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(d[4 * q] + fb), __float_as_uint(d[4 * q + 1] + fb),
+                                                                             __float_as_uint(d[4 * q + 2] + fb), __float_as_uint(d[4 * q + 3] + fb)},
+                                                                       rs_out, (int)voff, 32 * q, BBPC_STORE_AUX);
+                            }
+                        }
+                    }
                 } else {
                     static_for<NPL>([&](auto ic) { pf_write(ic, pnext); });
                 }
@@ -525,7 +529,7 @@ __device__ __forceinline__ void bbpc_body(const BBParams &p)
                 lds_barrier();
                 PSTAMP(4);
             }
-            finish(nloc - 1);
+            if constexpr (!FIN) finish(nloc - 1);
         };
         if (wj < 2) consumer_loop(std::integral_constant<int, 4>{});
         else consumer_loop(std::integral_constant<int, 3>{});

@@ -32,6 +32,7 @@ PlanSwitches PlanSwitches::from_env()
     s.poison_lds = on("HH_POISON_LDS");
     s.no_head_fold = on("HH_NO_HEAD_FOLD");
     s.no_conv_db = on("HH_NO_CONV_DB");
+    s.no_final_fuse = on("HH_NO_FINAL_FUSE");
     s.bb_tall = on("HH_NO_BB_TALL") ? 0 : is("HH_BB_TALL", "always") ? 2 : 1;
     if (const char *fc = getenv("HH_FAT_CUS")) { s.fat_cus = s.fat_cus64 = atoi(fc); if (const char *c2 = strchr(fc, ',')) s.fat_cus64 = atoi(c2 + 1); }
     if (const char *sk = getenv("HH_DEBUG_SKIP")) {
@@ -548,11 +549,18 @@ struct Builder {
             n.ops.push_back(q);
         }
         basic_blocks(dp + ".resid_blocks", C, DF, DM);
+        const int last_bb = (int)n.ops.size() - 1;
         tap("deconv#0", DF, C);
         {
             Op &o = conv(L(dp + ".final_layer", "", C, K, 1, 1, dp + ".final_layer.bias"), DF, -1, 0);
             o.f32_out = 2;
             o.hi = hi_heads; n.layers[o.layer].hi = hi_heads;
+            // bf16, 32 channels: the head runs in the last block's epilogue (basicblock_fused_pc.hip, FIN) and this op is skipped --
+            // decided per forward in enqueue() (not with taps on: "deconv#0" is the block output that is then never stored)
+            if (n.dtype != 2 && C == 32 && K <= 32 && n.ops[last_bb].kind == OP_BB) {
+                n.layers[o.layer].fin_head = true;
+                n.ops[last_bb].fin = (int)n.ops.size() - 1;
+            }
         }
     }
 };
@@ -764,6 +772,16 @@ int hh_net::finalize()
         HH_CHECK_HIP(hipMalloc((void **)&l.d_bias, (size_t)coutp * 4));
         HH_CHECK_HIP(hipMemcpy(l.d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
         HH_CHECK_HIP(hipMemcpy(l.d_bias, shift.data(), (size_t)coutp * 4, hipMemcpyHostToDevice));
+        if (l.fin_head) {  // B fragments of the head inside bbpc_final_kernel: lane (cout r, half h) of k half m holds cin 16m + 8h .. +7
+            std::vector<bf16_raw> wf(2 * 2 * 32 * 8, 0);
+            for (int m = 0; m < 2; ++m)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int co = 0; co < l.cout; ++co)
+                        for (int j = 0; j < 8; ++j) wf[(((m * 2 + hh) * 32) + co) * 8 + j] = f2bf(W[(size_t)co * l.cin + 16 * m + 8 * hh + j] * scale[co]);
+            if (l.d_wfin) { hipFree(l.d_wfin); l.d_wfin = nullptr; }
+            HH_CHECK_HIP(hipMalloc((void **)&l.d_wfin, wf.size() * 2));
+            HH_CHECK_HIP(hipMemcpy(l.d_wfin, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
+        }
     }
     if (kind == 1) {
         const auto &fw = get("classification_head.classifier.weight");
@@ -919,8 +937,10 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
     }
     int lanes_open = 1;  // lanes [0, lanes_open) have work that the caller's stream must wait for at the end
     hipEvent_t mark_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int fin_done = -1;  // index of the head conv that the last fused block has already run
     for (const Op &op : ops) {
         hipStream_t s = L[op.lane];
+        if (fin_done >= 0 && &op == &ops[fin_done]) continue;
         if (sw.debug_skip) {  // measurement only: the outputs are wrong
             unsigned cat = 0;
             if (op.kind == OP_UPADD) cat = SK_UPADD;
@@ -1139,6 +1159,12 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             p.w1 = l1.d_w; p.w2 = l2.d_w; p.b1 = l1.d_bias; p.b2 = l2.d_bias;
             p.B = B; p.H = H >> ti.shift; p.W = W >> ti.shift;
             p.tall = sw.bb_tall;
+            if (op.fin >= 0 && !sw.no_final_fuse && !sw.bb32_tile && !taps_enabled && o2 && !(sw.debug_skip & SK_HEAD)) {
+                const ConvLayer &lf = layers[ops[op.fin].layer];
+                p.fin_w = lf.d_wfin; p.fin_b = lf.d_bias; p.fin_out = o2; p.fin_K = lf.cout;
+                if (lf.d_wfin && bbpc_final_supported(p)) fin_done = op.fin;
+                else { p.fin_w = nullptr; p.fin_b = nullptr; p.fin_out = nullptr; p.fin_K = 0; }
+            }
             ProfRecord *pr = nullptr;
             if (prof_enabled) {
                 if (prof_used == prof.size()) {
@@ -1155,6 +1181,10 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 if (pr->slot >= 0 && prof_clk) p.clk = d_clk + 4 * pr->slot;
                 pr->flops = 2.0 * 2.0 * B * p.H * p.W * Cb * Cb * 9.0;
                 pr->bytes = 2.0 * B * p.H * p.W * Cb * 2 + 2.0 * 2 * 9 * Cb * Cb;
+                if (p.fin_out) {  // + the head: the block output stays on the chip, K fp32 planes leave instead
+                    pr->flops += 2.0 * B * p.H * p.W * Cb * p.fin_K;
+                    pr->bytes += (4.0 * p.fin_K - 2.0 * Cb) * B * p.H * p.W + 2.0 * Cb * p.fin_K;
+                }
                 hh_launch_probe() = LaunchProbe{pr->e0, pr->e1};  // the launch below stamps e0 / e1 from its dispatch packet
             }
             // inside an HR module with the lanes on: half the chip per fat kernel (PlanSwitches::fat_cus); alone: all of it
@@ -1442,6 +1472,7 @@ hh_net::~hh_net()
         if (l.d_w) hipFree(l.d_w);
         if (l.d_bias) hipFree(l.d_bias);
         if (l.d_mult) hipFree(l.d_mult);
+        if (l.d_wfin) hipFree(l.d_wfin);
     }
     if (d_amax) hipFree(d_amax);
 }

@@ -52,6 +52,8 @@ struct ConvLayer {
     int db = 0;  // 1: the double-buffered instantiation (3x3 stride 1, >= 128 input channels; PlanSwitches::no_conv_db)
     bf16_raw *d_w = nullptr;
     float *d_bias = nullptr;
+    bool fin_head = false;      // the deconv head's final 1x1: also packed as the B fragments of bbpc_final_kernel ([k half][lane half][32 couts][8])
+    bf16_raw *d_wfin = nullptr;
     // fp8 path: e4m3 weights with one scale per output channel; d_mult[co] = s_in * w_scale[co] is rewritten whenever the
     // activation scales change (calibration)
     std::vector<float> w_scale;
@@ -92,6 +94,7 @@ struct Op {
     int tap = -1;
     bool res8 = false;  // fp8 handle: this conv's residual stays e4m3 (stage 0's 256-channel trunk: its 1x1 convs are HBM-bound and a bf16
                         // twin would triple their traffic; emulation: +0.3-0.5 % rms at the outputs)
+    int fin = -1;  // OP_BB: index of the 1x1 head conv right behind this block that bbpc_final_kernel runs in the block's epilogue (-1: none)
     bool siblings = false;  // OP_BB: a block of an HR module with other branches beside it (its persistent grid takes half the CUs)
     bool hi = false;  // fp8 handle: OP_CONV on the bf16 kernels over the tensors' bf16 representations; OP_QUANT: tensor `out`'s bf16 -> e4m3
     int lane = 0;     // execution lane (HIP stream): resolution branches / fusion outputs run concurrently
@@ -144,6 +147,7 @@ struct PlanSwitches {
     // lanes find free CUs while either runs: forward 4.48 -> 4.39 ms, +1.5-2 % img/s (three alternations, profiles/r03_ab.md).
     // HH_FAT_CUS=n[,m] sets them (256 = one per CU, the round-2 plan); a quarter of the chip for the 64-channel block loses 6 %.
     int fat_cus = 0, fat_cus64 = 0;
+    bool no_final_fuse = false;    // HH_NO_FINAL_FUSE=1: the deconv head's final 1x1 as its own launch (round 4: it runs in the last block's epilogue)
     int bb_tall = 1;               // the fused 32-channel block tiles the batch as one tall image when that needs fewer tiles (round 4);
                                    // HH_NO_BB_TALL=1: per-image tiles (round 3), HH_BB_TALL=always: also where it needs more
     bool no_conv_db = false;       // HH_NO_CONV_DB=1: the 128- / 256-channel 3x3 convs on the single-buffer KC = 32 instantiations (round 2)

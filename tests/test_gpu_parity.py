@@ -219,6 +219,37 @@ def test_schedule_and_fusion_switches(pkg, net_golden):
         assert all(torch.equal(a, b) for a, b in zip(plain.forward_raw(xs), tall)), shape
 
 
+def test_final_layer_in_the_last_block_epilogue(pkg, net_golden):
+    """(round 4) DeconvHeatmapsHead.final_layer (1x1, 32 -> 17, higher_hrnet.py:38-44) runs inside the last residual block's kernel
+    (bbpc_final_kernel: the block output never goes to HBM) unless HH_NO_FINAL_FUSE=1 or taps are on.  Same bf16 operands, same
+    fp32 accumulation over the same 32 channels in the same two MFMA steps, the bias added last instead of first: the half-resolution
+    heatmaps agree to fp32 rounding (and meet the golden tolerance either way), everything else bit for bit.  Shapes: the golden one,
+    the tall layout's (4 x 512 x 512), ragged tiles, a single tile."""
+    os.environ["HH_NO_FINAL_FUSE"] = "1"
+    try:
+        plain, _ = _net(pkg, 32, 1)
+    finally:
+        del os.environ["HH_NO_FINAL_FUSE"]
+    fused, _ = _net(pkg, 32, 1)
+    x = torch.from_numpy(pkg.synth.synth_images(2, 128, 128, 1)).to(DEV)
+    for net in (fused, plain):
+        hms, _tags = net(x)
+        _close(hms[1].cpu().numpy(), net_golden["w32_128/hm_h"], "hm_h")
+    worst = 0.0
+    for i, shape in enumerate(((2, 128, 128), (4, 512, 512), (5, 352, 416), (3, 96, 160), (1, 32, 64), (1, 64, 32))):
+        xs = torch.from_numpy(pkg.synth.synth_images(*shape, 40 + i)).to(DEV)
+        a = [t.clone() for t in fused.forward_raw(xs)]
+        b = [t.clone() for t in plain.forward_raw(xs)]
+        assert torch.equal(a[0], b[0]), shape  # init heatmaps + tags: untouched by the fusion
+        assert a[1].shape == b[1].shape and torch.isfinite(a[1]).all(), shape
+        d = (a[1] - b[1]).abs().max().item() / b[1].abs().max().item()
+        worst = max(worst, d)
+        assert d <= 2e-6, (shape, d)  # fp32 rounding of (sum + bias) against (bias + sum)
+        c = [t.clone() for t in fused.forward_raw(xs)]
+        assert torch.equal(a[1], c[1]), shape  # and it is deterministic
+    print(f"fused final layer vs its own launch: max |diff| / max |ref| = {worst:.2e}")
+
+
 def test_forward_reads_no_unwritten_workspace(pkg):
     """Recycled device memory is not zero: with the workspace filled with NaN patterns at allocation (HH_POISON_WS=1) the forward
     must give the bits it gives on fresh memory, for growing and shrinking shapes on one handle."""
