@@ -33,6 +33,7 @@ PlanSwitches PlanSwitches::from_env()
     s.no_head_fold = on("HH_NO_HEAD_FOLD");
     s.no_conv_db = on("HH_NO_CONV_DB");
     s.no_final_fuse = on("HH_NO_FINAL_FUSE");
+    s.early_wait = on("HH_EARLY_WAIT");
     s.bb_tall = on("HH_NO_BB_TALL") ? 0 : is("HH_BB_TALL", "always") ? 2 : 1;
     if (const char *fc = getenv("HH_FAT_CUS")) { s.fat_cus = s.fat_cus64 = atoi(fc); if (const char *c2 = strchr(fc, ',')) s.fat_cus64 = atoi(c2 + 1); }
     if (const char *sk = getenv("HH_DEBUG_SKIP")) {
@@ -381,6 +382,14 @@ struct Builder {
                 // every output waits, source by source, right in front of the first launch that needs the source
                 // (HH_FULL_JOIN=1: an all-to-all join here instead)
                 const bool fine = !n.sw.full_join;
+                const bool early = fine && n.sw.early_wait && n.dtype != 2;
+                if (early) {  // [mark lanes 0..nsc-2, lane nsc-1 waits for each] in front of the last launch of lane nsc-1
+                    const Op last_op = n.ops.back();
+                    n.ops.pop_back();
+                    mark(nsc - 1);
+                    for (int j = 0; j < nsc - 1; ++j) waitl(nsc - 1, j);
+                    n.ops.push_back(last_op);
+                }
                 if (fine) mark(nsc); else join(nsc);
                 for (int i = 0; i < nsc; ++i)
                     tap("stages." + std::to_string(s) + ".blocks." + std::to_string(2 * b) + "#" + std::to_string(i), x[i], w[i]);
@@ -394,6 +403,7 @@ struct Builder {
                     int cur = x[i];
                     bool waited[4] = {false, false, false, false};
                     waited[i] = true;
+                    if (early && i == nsc - 1) waited[0] = waited[1] = waited[2] = waited[3] = true;
                     auto need = [&](int j) { if (fine && !waited[j]) { waitl(i, j); waited[j] = true; } };
                     // OUT is the x[i] of the previous HR block, which the other lanes' fusion launches read then: before the first
                     // write to it this lane must be behind every other lane's mark (which is behind those reads)
