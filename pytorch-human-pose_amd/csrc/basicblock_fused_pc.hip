@@ -103,8 +103,14 @@ constexpr int MID_BYTES = MH * MW * 64;     // 34,816
 constexpr int P_UNITS = IH * IW * 4;        // 2592 16-byte units
 constexpr int NPL = (P_UNITS + NTHR - 1) / NTHR;  // 6 (the last round: 32 threads)
 // LDS fragment reads run RD steps (1-3 MFMAs each) ahead of the MFMAs that use them
-constexpr int RD = 2, NFB = RD + 1;     // producer
-constexpr int RDC = 4, NFBC = RDC + 1;  // consumer (more registers to spare)
+#ifndef BBPC_RD
+#define BBPC_RD 2
+#endif
+#ifndef BBPC_RDC
+#define BBPC_RDC 4
+#endif
+constexpr int RD = BBPC_RD, NFB = RD + 1;     // producer
+constexpr int RDC = BBPC_RDC, NFBC = RDC + 1;  // consumer (more registers to spare)
 constexpr int RP = MH / 4;                  // mid rows per producer wave
 static_assert(MH % 4 == 0 && 2 * MH == 32, "4 producer bands; the two extra mid columns make exactly one 32-pixel column tile");
 constexpr int OFF_MID = 2 * PATCH_BYTES, OFF_BIAS = OFF_MID + 2 * MID_BYTES;

@@ -907,6 +907,16 @@ hipError_t launch_munkres_debug(const double *cost, int n, int32_t *out, hipStre
     return hipGetLastError();
 }
 
+#ifdef HH_MATCH_STAMP  // diagnostic build (tools/probes/match_stamps.sh): cycle stamps of image 0's wave, 8 per joint
+__device__ unsigned long long g_match_stamps[32 * 8];
+#define MSTAMP(i) do { if (b == 0 && lane == 0) g_match_stamps[it * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int hh_debug_match_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_match_stamps), sizeof(g_match_stamps));
+}
+#else
+#define MSTAMP(i)
+#endif
 __constant__ int c_joints_order[17] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 7, 8, 9, 10, 13, 14, 15, 16};  // grouping.py:63-65
 
 __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const int32_t *coords_k, const float *scores_k, int K, int M, int E,
@@ -941,6 +951,7 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
     int bad = 0;
     for (int it = 0; it < K; ++it) {
         const int idx = K == 17 ? c_joints_order[it] : it;
+        MSTAMP(0);
         // candidates with score > det_thr, order kept (grouping.py:98-102)
         float s = 0.f;
         bool keep = false;
@@ -955,6 +966,7 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
             for (int e = 0; e < E; ++e) S.ctag[a * HH_MAX_EMB + e] = tags_k[(idx * M + lane) * E + e];
         }
         __syncthreads();
+        MSTAMP(1);
         if (na == 0) continue;
         const int G = S.G;
         const bool first = (it == 0) || (G == 0);
@@ -967,6 +979,7 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
                 else np_mean_rows(GT + (size_t)lane * (K + 1) * E, nt, E, &S.gmean[lane * HH_MAX_EMB]);
             }
             __syncthreads();
+            MSTAMP(2);
             const int n = na > ng ? na : ng;
             const float inv_n = 1.0f / (float)n;
             for (int i = lane; i < n * n; i += 64) {
@@ -991,10 +1004,12 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
                 S.Cm[a * MLD + g] = c;
             }
             __syncthreads();
+            MSTAMP(3);
             int star = -1;
             bad |= munkres_wave(S, n, lane, star);
             if (lane < na) S.assign[lane] = star;
             __syncthreads();
+            MSTAMP(4);
         }
         // dict semantics of grouping.py:104-143.  A candidate matched to a group appends to that group only (the assignment is
         // one-to-one), so the matched ones are applied by their own lanes; what must stay in candidate order on lane 0 are the
@@ -1036,6 +1051,7 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
                 __syncthreads();
             }
         }
+        MSTAMP(5);
         {   // candidates in row order; the loop is wave-uniform: the search for an existing key is one ballot over the groups' keys
             // (lane q holds the key of group q) instead of a scan on one lane, lane 0 does the writes
             int Gc = S.G;
@@ -1070,6 +1086,7 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
             if (lane == 0) S.G = Gc;
         }
         __syncthreads();
+        MSTAMP(6);
     }
     if (lane == 0) {
         int P = S.G;
