@@ -33,7 +33,7 @@ PlanSwitches PlanSwitches::from_env()
     s.no_head_fold = on("HH_NO_HEAD_FOLD");
     s.no_conv_db = on("HH_NO_CONV_DB");
     s.no_final_fuse = on("HH_NO_FINAL_FUSE");
-    s.early_wait = on("HH_EARLY_WAIT");
+    s.keep_waits = on("HH_KEEP_WAITS");
     s.bb_tall = on("HH_NO_BB_TALL") ? 0 : is("HH_BB_TALL", "always") ? 2 : 1;
     if (const char *fc = getenv("HH_FAT_CUS")) { s.fat_cus = s.fat_cus64 = atoi(fc); if (const char *c2 = strchr(fc, ',')) s.fat_cus64 = atoi(c2 + 1); }
     if (const char *sk = getenv("HH_DEBUG_SKIP")) {
@@ -94,10 +94,10 @@ struct Builder {
     // mark / waitl: a join taken apart.  mark(n) notes where every lane stands; waitl(lane, src) makes `lane` wait for lane
     // `src`'s position at the last mark only -- a fusion output starts on the branches that are already done instead of waiting
     // for the slowest one.
-    void mark(int nlanes)
+    void mark(int nlanes, int first = 0)  // lanes [first, nlanes) note their positions
     {
         Op o;
-        o.kind = OP_MARK; o.nlanes = nlanes;
+        o.kind = OP_MARK; o.nlanes = nlanes; o.dep_from = first;
         n.ops.push_back(o);
     }
     void waitl(int lane_, int src)
@@ -382,14 +382,9 @@ struct Builder {
                 // every output waits, source by source, right in front of the first launch that needs the source
                 // (HH_FULL_JOIN=1: an all-to-all join here instead)
                 const bool fine = !n.sw.full_join;
-                const bool early = fine && n.sw.early_wait && n.dtype != 2;
-                if (early) {  // [mark lanes 0..nsc-2, lane nsc-1 waits for each] in front of the last launch of lane nsc-1
-                    const Op last_op = n.ops.back();
-                    n.ops.pop_back();
-                    mark(nsc - 1);
-                    for (int j = 0; j < nsc - 1; ++j) waitl(nsc - 1, j);
-                    n.ops.push_back(last_op);
-                }
+                // (Measured and dropped in round 4, profiles/r04_ab.md 8.3: the slowest lane waiting in front of its last block launch,
+                // +0.1 ms; a chain join with one wait per lane instead of source-by-source waits, +0.12 ms -- the early starts on the
+                // sources that are already done are worth more than the waits they cost.)
                 if (fine) mark(nsc); else join(nsc);
                 for (int i = 0; i < nsc; ++i)
                     tap("stages." + std::to_string(s) + ".blocks." + std::to_string(2 * b) + "#" + std::to_string(i), x[i], w[i]);
@@ -403,7 +398,6 @@ struct Builder {
                     int cur = x[i];
                     bool waited[4] = {false, false, false, false};
                     waited[i] = true;
-                    if (early && i == nsc - 1) waited[0] = waited[1] = waited[2] = waited[3] = true;
                     auto need = [&](int j) { if (fine && !waited[j]) { waitl(i, j); waited[j] = true; } };
                     // OUT is the x[i] of the previous HR block, which the other lanes' fusion launches read then: before the first
                     // write to it this lane must be behind every other lane's mark (which is behind those reads)
@@ -947,10 +941,22 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
     }
     int lanes_open = 1;  // lanes [0, lanes_open) have work that the caller's stream must wait for at the end
     hipEvent_t mark_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // What each lane is already ordered behind, as vector clocks over the launches enqueued so far (check_plan's model, kept while
+    // enqueueing): a wait whose event names nothing newer is dropped.  A wait is a barrier packet that costs its stream ~11 us even
+    // if the event completed long before (tools/probes/event_cost.py) -- e.g. the closing edges for lanes that lane 0 has joined already.
+    int seqn[4] = {0, 0, 0, 0}, vc[4][4] = {}, mark_snap[4][4] = {};
+    auto snap = [&](int l, int *out) { for (int m = 0; m < 4; ++m) out[m] = m == l ? seqn[l] : vc[l][m]; };
+    auto news = [&](int l, const int *sn) {  // does the snapshot hold anything lane l is not behind yet?  (then: l is behind it from now on)
+        bool any = false;
+        for (int m = 0; m < 4; ++m)
+            if (m != l && sn[m] > vc[l][m]) { vc[l][m] = sn[m]; any = true; }
+        return any;
+    };
     int fin_done = -1;  // index of the head conv that the last fused block has already run
     for (const Op &op : ops) {
         hipStream_t s = L[op.lane];
         if (fin_done >= 0 && &op == &ops[fin_done]) continue;
+        if (op.kind != OP_JOIN && op.kind != OP_MARK && op.kind != OP_WAITL && op.kind != OP_DEP) ++seqn[op.lane];  // (a launch, or nothing: over-counting only keeps a wait)
         if (sw.debug_skip) {  // measurement only: the outputs are wrong
             unsigned cat = 0;
             if (op.kind == OP_UPADD) cat = SK_UPADD;
@@ -982,9 +988,11 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
                 if (next_event(&e[l])) return 1;
                 HH_CHECK_HIP(hipEventRecord(e[l], L[l]));
             }
+            int sn[4][4];
+            for (int m = 0; m < nrec; ++m) snap(m, sn[m]);
             for (int l = 0; l < op.nlanes; ++l)
                 for (int m = 0; m < nrec; ++m)
-                    if (m != l) HH_CHECK_HIP(hipStreamWaitEvent(L[l], e[m], 0));
+                    if (m != l) { news(l, sn[m]); HH_CHECK_HIP(hipStreamWaitEvent(L[l], e[m], 0)); }
             if (op.nlanes > lanes_open) lanes_open = op.nlanes;
             break;
         }
@@ -992,9 +1000,10 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
             if (!multi) break;
             const int nrec = op.nlanes < lanes_open ? op.nlanes : lanes_open;
             for (int l = 0; l < 4; ++l) mark_ev[l] = nullptr;  // a wait may only name a lane THIS mark recorded
-            for (int l = 0; l < nrec; ++l) {
+            for (int l = op.dep_from; l < nrec; ++l) {
                 if (next_event(&mark_ev[l])) return 1;
                 HH_CHECK_HIP(hipEventRecord(mark_ev[l], L[l]));
+                snap(l, mark_snap[l]);
             }
             if (op.nlanes > lanes_open) lanes_open = op.nlanes;
             break;
@@ -1002,11 +1011,15 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         case OP_WAITL: {
             if (!multi) break;
             if (!mark_ev[op.dep_from]) { hh_set_error("plan: OP_WAITL names a lane the last OP_MARK did not record"); return 1; }
+            if (!news(op.lane, mark_snap[op.dep_from]) && !sw.keep_waits) break;  // already behind it
             HH_CHECK_HIP(hipStreamWaitEvent(L[op.lane], mark_ev[op.dep_from], 0));
             break;
         }
         case OP_DEP: {
             if (!multi) break;
+            int sn[4];
+            snap(op.dep_from, sn);
+            if (!news(op.lane, sn) && !sw.keep_waits) break;
             hipEvent_t e;
             if (next_event(&e)) return 1;
             HH_CHECK_HIP(hipEventRecord(e, L[op.dep_from]));
@@ -1299,7 +1312,10 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
         }
     }
     if (multi)
-        for (int l = 1; l < lanes_open; ++l) {  // close the fork: the caller's stream waits for every lane
+        for (int l = 1; l < lanes_open; ++l) {  // close the fork: the caller's stream waits for every lane it is not behind yet
+            int sn[4];
+            snap(l, sn);
+            if (!news(0, sn) && !sw.keep_waits) continue;
             hipEvent_t e;
             if (next_event(&e)) return 1;
             HH_CHECK_HIP(hipEventRecord(e, L[l]));
@@ -1380,8 +1396,8 @@ int hh_net::check_plan(std::string *why) const
         }
         if (op.kind == OP_MARK) {
             const int nrec = op.nlanes < lanes_open ? op.nlanes : lanes_open;
-            for (int m = 0; m < 4; ++m) mark_ok[m] = m < nrec;
-            for (int m = 0; m < nrec; ++m)
+            for (int m = 0; m < 4; ++m) mark_ok[m] = m >= op.dep_from && m < nrec;
+            for (int m = op.dep_from; m < nrec; ++m)
                 for (int c = 0; c < 4; ++c) mark_clk[m][c] = clk[m][c];
             if (op.nlanes > lanes_open) lanes_open = op.nlanes;
             continue;
