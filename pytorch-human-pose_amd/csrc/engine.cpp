@@ -384,7 +384,8 @@ struct Builder {
                 const bool fine = !n.sw.full_join;
                 // (Measured and dropped in round 4, profiles/r04_ab.md 8.3: the slowest lane waiting in front of its last block launch,
                 // +0.1 ms; a chain join with one wait per lane instead of source-by-source waits, +0.12 ms -- the early starts on the
-                // sources that are already done are worth more than the waits they cost.)
+                // sources that are already done are worth more than the waits they cost; the lane above the lowest one handing it ONE
+                // event for all higher lanes: neutral.)
                 if (fine) mark(nsc); else join(nsc);
                 for (int i = 0; i < nsc; ++i)
                     tap("stages." + std::to_string(s) + ".blocks." + std::to_string(2 * b) + "#" + std::to_string(i), x[i], w[i]);

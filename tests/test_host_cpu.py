@@ -230,7 +230,7 @@ def test_multi_lane_schedule_has_no_unordered_hazard(pkg):
         assert lib.hh_debug_check_plan(net._h) == 0, lib.hh_last_error().decode()
     # the plan variants behind the engine switches (read once, in hh_create, into the handle) and the fp8 plan
     import os
-    for env in ({"HH_NO_FUSION_MERGE": "1"}, {"HH_FULL_JOIN": "1"}, {"HH_FULL_JOIN": "1", "HH_NO_FUSION_MERGE": "1"}, {"HH_NO_STEM_FUSED": "1"}, {"HH_NO_JUNC_PAIR": "1"}, {"HH_NO_JUNC_PAIR": "1", "HH_FULL_JOIN": "1"}, {"HH_NO_HEAD_FOLD": "1"}, {"HH_BB32": "tile", "HH_NO_BB64": "1"}, {"HH_NO_CONV_DB": "1"}):
+    for env in ({"HH_NO_FUSION_MERGE": "1"}, {"HH_FULL_JOIN": "1"}, {"HH_FULL_JOIN": "1", "HH_NO_FUSION_MERGE": "1"}, {"HH_NO_STEM_FUSED": "1"}, {"HH_NO_JUNC_PAIR": "1"}, {"HH_NO_JUNC_PAIR": "1", "HH_FULL_JOIN": "1"}, {"HH_NO_HEAD_FOLD": "1"}, {"HH_BB32": "tile", "HH_NO_BB64": "1"}, {"HH_NO_CONV_DB": "1"}, {"HH_KEEP_WAITS": "1"}):
         os.environ.update(env)
         try:
             nets = (pkg.HigherHRNet(17, 32), pkg.HigherHRNet(17, 48))
