@@ -51,6 +51,9 @@ __device__ __forceinline__ void add_rows16(f32x16 &acc, const u32x4 v[2])
         acc[8 * m + 6] += bf16_lo(s1[1]); acc[8 * m + 7] += bf16_hi(s1[1]);
     }
 }
+#ifndef JUNC_PREFETCH
+#define JUNC_PREFETCH 1
+#endif
 constexpr int W3_BYTES = 256 * 64 * 2;  // conv3 / downsample: packed [cout group 4][chunk 2][c8 4][64][8] (conv_mfma family, NT = 2)
 constexpr int W1_BYTES = 64 * 256 * 2;  // next conv1: packed [chunk 8][c8 4][64][8]
 }  // namespace
@@ -95,17 +98,36 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, (MODE == 0 || MODE == 3) ? 2
 
     constexpr int GP = NT / 2;  // pixels per workgroup step: 32 per wave
     const int ngroups = (p.npix + GP - 1) / GP;
+    // pixel fragments (B operands) of a group.  MODE 2 loads them one group AHEAD (round 4): its workgroup is alone on the CU, one wave per
+    // SIMD, and every group began with a full HBM round trip in front of its first MFMA that nobody covered: 152 -> 125 us.  (The
+    // other modes run two waves per SIMD, which cover each other: 1-2 us SLOWER with the 16-48 more registers, MODE 3 spills.)
+    constexpr bool PF = JUNC_PREFETCH && MODE == 2;
+    struct Frags { u32x4 bt[4], bx[HAS_DS ? 4 : 1], bta[PAIR ? 4 : 1]; };
+    auto load_frags = [&](int g, Frags &f) {
+        const int pixn = g * GP + wave * 32 + r;
+        const size_t px = pixn < p.npix ? pixn : 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f.bt[s] = *reinterpret_cast<const u32x4 *>(p.t2 + px * p.t2_cs + s * 16 + h * 8);
+            if (HAS_DS) f.bx[s] = *reinterpret_cast<const u32x4 *>(p.x + px * p.x_cs + s * 16 + h * 8);
+            if (PAIR) f.bta[s] = *reinterpret_cast<const u32x4 *>(p.t2a + px * p.t2a_cs + s * 16 + h * 8);
+        }
+    };
+    Frags fnext;
+    if (PF && (int)blockIdx.x < ngroups) load_frags(blockIdx.x, fnext);
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int pix = g * GP + wave * 32 + r;
         const bool valid = pix < p.npix;
         const size_t px = valid ? pix : 0;
-        // ---- loads: pixel fragments (B operands) first
-        u32x4 bt[4], bx[HAS_DS ? 4 : 1], bta[PAIR ? 4 : 1];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bt[s] = *reinterpret_cast<const u32x4 *>(p.t2 + px * p.t2_cs + s * 16 + h * 8);
-            if (HAS_DS) bx[s] = *reinterpret_cast<const u32x4 *>(p.x + px * p.x_cs + s * 16 + h * 8);
-            if (PAIR) bta[s] = *reinterpret_cast<const u32x4 *>(p.t2a + px * p.t2a_cs + s * 16 + h * 8);
+        Frags fcur;
+        if (PF) fcur = fnext;
+        else load_frags(g, fcur);
+        const u32x4 (&bt)[4] = fcur.bt;
+        const u32x4 (&bx)[HAS_DS ? 4 : 1] = fcur.bx;
+        const u32x4 (&bta)[PAIR ? 4 : 1] = fcur.bta;
+        {
+            const int gn = g + (int)gridDim.x;
+            if (PF && gn < ngroups) load_frags(gn, fnext);
         }
         // ---- GEMM 1 in two halves of 128 output channels (64 accumulator registers live at a time):
         //      y[256] = W3 t2 (+ Wd x) + shift (+ residual), ReLU, bf16; y leaves for HBM and stays in registers (yf) as the
