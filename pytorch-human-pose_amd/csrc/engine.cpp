@@ -32,7 +32,6 @@ PlanSwitches PlanSwitches::from_env()
     s.poison_lds = on("HH_POISON_LDS");
     s.no_head_fold = on("HH_NO_HEAD_FOLD");
     s.no_conv_db = on("HH_NO_CONV_DB");
-    if (const char *v = getenv("HH_CONV_DB_MIN_CIN")) s.conv_db_min_cin = atoi(v);
     s.no_final_fuse = on("HH_NO_FINAL_FUSE");
     s.keep_waits = on("HH_KEEP_WAITS");
     s.bb_tall = on("HH_NO_BB_TALL") ? 0 : is("HH_BB_TALL", "always") ? 2 : 1;
@@ -668,9 +667,6 @@ int hh_net::finalize()
         num_cus = prop.multiProcessorCount;
     }
     auto get = [&](const std::string &name) -> const std::vector<float> & { return params[param_index.at(name)].data; };
-    std::vector<char> in_bb(layers.size(), 0);  // layers of fused BasicBlocks: their kernels fix the weight layout
-    for (const Op &op : ops)
-        if (op.kind == OP_BB) { in_bb[op.layer] = 1; in_bb[op.layer2] = 1; }
     for (auto &l : layers) {
         if (l.stem) {  // [cout tile 2][k-step 2][half 2][32][8], tap = c*9 + ky*3 + kx, BN scale folded
             const std::vector<float> &W = get(l.conv + ".weight");
@@ -702,7 +698,7 @@ int hh_net::finalize()
             return 1;
         }
         // the wide 3x3 layers (one wave per SIMD, 8+ chunks): 16-channel chunks on two LDS buffers (conv_mfma.hip, DB)
-        l.db = !sw.no_conv_db && !l.stem2 && l.ks == 3 && l.stride == 1 && !l.transposed && l.mconv.empty() && l.cin >= sw.conv_db_min_cin && !in_bb[&l - layers.data()] &&
+        l.db = !sw.no_conv_db && !l.stem2 && l.ks == 3 && l.stride == 1 && !l.transposed && l.mconv.empty() && l.cin >= 128 &&
                l.cin % 16 == 0 && coutp % 64 == 0;
         if (l.db) { l.KC = 16; l.NT = 2; }
         l.cin_pad = round_up(l.cin, l.KC);

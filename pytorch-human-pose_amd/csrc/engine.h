@@ -151,7 +151,6 @@ struct PlanSwitches {
     bool no_final_fuse = false;    // HH_NO_FINAL_FUSE=1: the deconv head's final 1x1 as its own launch (round 4: it runs in the last block's epilogue)
     int bb_tall = 1;               // the fused 32-channel block tiles the batch as one tall image when that needs fewer tiles (round 4);
                                    // HH_NO_BB_TALL=1: per-image tiles (round 3), HH_BB_TALL=always: also where it needs more
-    int conv_db_min_cin = 128;     // HH_CONV_DB_MIN_CIN: narrowest 3x3 stride-1 layer that takes the double-buffered 16-channel-chunk form
     bool no_conv_db = false;       // HH_NO_CONV_DB=1: the 128- / 256-channel 3x3 convs on the single-buffer KC = 32 instantiations (round 2)
     bool no_head_fold = false;     // HH_NO_HEAD_FOLD=1: init_heatmaps_head writes its output into the concat buffer, the transposed conv reads it
     bool poison_lds = false;       // HH_POISON_LDS=1 (tests): every CU's LDS filled with NaN patterns in front of every launch
