@@ -1059,6 +1059,7 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
             for (u64 sm = serial; sm; sm &= sm - 1) {
                 const int a = __builtin_ctzll(sm);
                 int t;
+                bool fresh = false;  // a new (or reset) tag list: its length is known to be 0, no LDS round trips to find out
                 const int col = first ? -1 : S.assign[a];
                 if (!first && col >= 0 && col < ng && S.saved[a * MLD + col] < tag_thr) t = col;
                 else {
@@ -1071,16 +1072,17 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
                         if (lane == t) gkreg = key;
                         if (lane == 0) S.gkey[t] = key;
                     }
-                    if (lane == 0) S.gnt[t] = 0;
+                    fresh = true;
                 }
                 if (lane == 0) {
+                    const int pos = fresh ? 0 : S.gnt[t];
                     float *jr = J + ((size_t)t * K + idx) * D;
                     jr[0] = (float)S.cj[a * 3 + 0]; jr[1] = (float)S.cj[a * 3 + 1]; jr[2] = (float)S.cj[a * 3 + 2];
                     for (int e = 0; e < E; ++e) {
                         jr[3 + e] = S.ctag[a * HH_MAX_EMB + e];
-                        GT[((size_t)t * (K + 1) + S.gnt[t]) * E + e] = S.ctag[a * HH_MAX_EMB + e];
+                        GT[((size_t)t * (K + 1) + pos) * E + e] = S.ctag[a * HH_MAX_EMB + e];
                     }
-                    S.gnt[t] += 1;
+                    S.gnt[t] = pos + 1;
                 }
             }
             if (lane == 0) S.G = Gc;
