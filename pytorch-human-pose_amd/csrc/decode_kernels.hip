@@ -965,9 +965,8 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
             S.cj[a * 3 + 2] = (double)s;
             for (int e = 0; e < E; ++e) S.ctag[a * HH_MAX_EMB + e] = tags_k[(idx * M + lane) * E + e];
         }
-        __syncthreads();
-        MSTAMP(1);
-        if (na == 0) continue;
+        // the groups' mean tags (grouping.py:107-108) in the same stretch as the candidate gather: they only need what the previous joint
+        // left (behind its closing barrier), and their LDS round trips overlap the gather's instead of following them behind a barrier
         const int G = S.G;
         const bool first = (it == 0) || (G == 0);
         int ng = 0;
@@ -978,7 +977,11 @@ __global__ __launch_bounds__(64) void match_kernel(const float *tags_k, const in
                 if (E == 1 && nt <= 18) S.gmean[lane * HH_MAX_EMB] = np_mean18(GT + (size_t)lane * (K + 1), nt);
                 else np_mean_rows(GT + (size_t)lane * (K + 1) * E, nt, E, &S.gmean[lane * HH_MAX_EMB]);
             }
-            __syncthreads();
+        }
+        __syncthreads();
+        MSTAMP(1);
+        if (na == 0) continue;
+        if (!first) {
             MSTAMP(2);
             const int n = na > ng ? na : ng;
             const float inv_n = 1.0f / (float)n;
