@@ -31,3 +31,14 @@ for b0, bl in bubbles:
     before = sorted([x for x in ev if x[1] <= b0 + 0.05], key=lambda x: -x[1])[:3]
     after = sorted([x for x in ev if x[0] >= b0 + bl - 0.05], key=lambda x: x[0])[:4]
     print(f"bubble at {b0} (+{bl}):  before:", [(round(e, 1), q, n.split('(')[0][-40:]) for s, e, q, n in before], " after:", [(round(s, 1), q, n.split('(')[0][-40:]) for s, e, q, n in after])
+# per-lane Gantt of the forward (start - end, duration, gap to the lane's previous launch): python tools/probes/timeline.py trace.csv gantt
+if len(sys.argv) > 2 and sys.argv[2] == "gantt":
+    def short(n):
+        return n.split("(")[0].replace("void ", "").replace("conv_mfma_kernel", "conv")[:34]
+    for q in sorted(set(e[2] for e in ev)):
+        print(f"--- queue {q}")
+        prev = None
+        for s, e, qq, n in ev:
+            if qq != q: continue
+            print(f"{s:8.1f} {e:8.1f} {e - s:6.1f} {('+%.0f' % (s - prev)) if prev is not None else '':>6s}  {short(n)}")
+            prev = e
