@@ -34,6 +34,7 @@ PlanSwitches PlanSwitches::from_env()
     s.no_conv_db = on("HH_NO_CONV_DB");
     s.no_final_fuse = on("HH_NO_FINAL_FUSE");
     s.keep_waits = on("HH_KEEP_WAITS");
+    s.event_system_fence = on("HH_EVENT_SYSTEM_FENCE");
     s.bb_tall = on("HH_NO_BB_TALL") ? 0 : is("HH_BB_TALL", "always") ? 2 : 1;
     if (const char *fc = getenv("HH_FAT_CUS")) { s.fat_cus = s.fat_cus64 = atoi(fc); if (const char *c2 = strchr(fc, ',')) s.fat_cus64 = atoi(c2 + 1); }
     if (const char *sk = getenv("HH_DEBUG_SKIP")) {
@@ -922,7 +923,10 @@ int hh_net::enqueue(const float *images, int B, int H, int W, float *o1, float *
     auto next_event = [&](hipEvent_t *e) -> int {
         if (lane_events_used == lane_events.size()) {
             hipEvent_t ne;
-            HH_CHECK_HIP(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+            // The lane events order streams of ONE device: no system-scope fence (cache write-back / invalidate for the host's and other
+            // devices' eyes) when one is recorded -- the caller's own synchronisation of its stream does that once, at the end.
+            // Round 4: forward 4.30 -> 4.27 ms (HH_EVENT_SYSTEM_FENCE=1: plain hipEventDisableTiming events).
+            HH_CHECK_HIP(hipEventCreateWithFlags(&ne, hipEventDisableTiming | (sw.event_system_fence ? 0u : (unsigned)hipEventDisableSystemFence)));
             lane_events.push_back(ne);
         }
         *e = lane_events[lane_events_used++];

@@ -147,6 +147,7 @@ struct PlanSwitches {
     // lanes find free CUs while either runs: forward 4.48 -> 4.39 ms, +1.5-2 % img/s (three alternations, profiles/r03_ab.md).
     // HH_FAT_CUS=n[,m] sets them (256 = one per CU, the round-2 plan); a quarter of the chip for the 64-channel block loses 6 %.
     int fat_cus = 0, fat_cus64 = 0;
+    bool event_system_fence = false;  // HH_EVENT_SYSTEM_FENCE=1: the lane events with the default system-scope fence at record time
     bool keep_waits = false;       // HH_KEEP_WAITS=1: enqueue() issues every wait of the plan, also those it can prove redundant (A/B)
     bool no_final_fuse = false;    // HH_NO_FINAL_FUSE=1: the deconv head's final 1x1 as its own launch (round 4: it runs in the last block's epilogue)
     int bb_tall = 1;               // the fused 32-channel block tiles the batch as one tall image when that needs fewer tiles (round 4);

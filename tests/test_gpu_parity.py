@@ -192,7 +192,7 @@ def test_schedule_and_fusion_switches(pkg, net_golden):
     # where it needs more tiles than the per-image layout and is not chosen; HH_NO_BB_TALL=1: never): other tiles, the same sums
     for env, exact in ((("HH_FULL_JOIN", "1"), True), (("HH_NO_FUSION_MERGE", "1"), False), (("HH_NO_JUNC_PAIR", "1"), True), (("HH_NO_CONV_DB", "1"), False),
                        (("HH_BB_TALL", "always"), True), (("HH_NO_BB_TALL", "1"), True),
-                       (("HH_KEEP_WAITS", "1"), True)):  # (round 4) enqueue() drops the waits its vector clocks prove redundant: the same launches either way
+                       (("HH_KEEP_WAITS", "1"), True), (("HH_EVENT_SYSTEM_FENCE", "1"), True)):  # (round 4) enqueue() drops the waits its vector clocks prove redundant: the same launches either way
         os.environ[env[0]] = env[1]
         try:
             net, _ = _net(pkg, 32, 1)
