@@ -1342,7 +1342,9 @@ def test_fp8_chained_forward_decode(pkg):
         e4m3; relative step 2^-3, i.e. <= 6.25 % per rounding) -- the fp8 convs beside them leak nothing
         into the reserved channels and every scale is applied and undone correctly;
       * hh_decode of the fp8 maps equals the oracle's decode of those same maps bit for bit;
-      * NOT the fp32 grouping: a value CARRIED through an e4m3 tensor is rounded to 3 mantissa bits, which turns the smooth top of
+      * no person is lost: every person the fp32 maps decode to has an fp8 counterpart holding >= 80 % of its detected joints within
+        2 px (measured: 94 %);
+      * NOT the fp32 group COUNT: a value CARRIED through an e4m3 tensor is rounded to 3 mantissa bits, which turns the smooth top of
         a blob into a plateau of equal values, and every plateau pixel survives `maxpool == hm` as a peak (tools/probes/
         fp8_emulate.py-style check on the CPU oracle: rounding only the carried inputs to e4m3 already turns 6 / 4 / 1 / 4 groups
         into 10 / 8 / 2 / 8).  That is an artefact of carrying values through activations; a trained net's heatmaps come out of the
@@ -1370,12 +1372,28 @@ def test_fp8_chained_forward_decode(pkg):
     parser = pkg.MPPEHeatmapParser(17, 30, 0.05, 0.5)
     got = parser.to_lists(*parser.decode_batch_device(g_hq, g_hh, [g_tags]))
     counts = []
+    worst_cover = 1.0
+    FP8_MIN_COVER = 0.8  # measured 0.94: every reference person's detected joints reappear, within 2 px, in ONE fp8 person
     for b in range(B):
         rj, _ = orc.decode(r_hq[b].numpy(), r_hh[b].numpy(), [r_tags[b].numpy()], max_people=30, det_thr=0.05, tag_thr=0.5)
         oj, os_ = orc.decode(g_hq[b].cpu().numpy(), g_hh[b].cpu().numpy(), [g_tags[b].cpu().numpy()], max_people=30, det_thr=0.05, tag_thr=0.5)
         assert np.array_equal(got[b][0], oj) and np.array_equal(got[b][1], os_), b
         counts.append((rj.shape[0], oj.shape[0]))
-    print("fp8 chained: groups (fp32 oracle, fp8 engine) per image:", counts)
+        # task-level statement that CAN be made on carried values: no person is lost.  Every person the fp32 maps decode to has a
+        # counterpart in the fp8 decode -- the fp8 person that shares most of its detected joints within 2 px (the plateaus add
+        # duplicate groups around the same blobs, they do not move them)
+        for pr in rj:
+            det = pr[:, 2] > 0
+            if not det.any():
+                continue
+            best = 0.0
+            for po in oj:
+                both = det & (po[:, 2] > 0)
+                near = both & (np.abs(po[:, 0] - pr[:, 0]) <= 2.0) & (np.abs(po[:, 1] - pr[:, 1]) <= 2.0)
+                best = max(best, near.sum() / det.sum())
+            worst_cover = min(worst_cover, best)
+    print("fp8 chained: groups (fp32 oracle, fp8 engine) per image:", counts, " least share of a reference person's joints found in one fp8 person:", round(worst_cover, 3))
+    assert worst_cover >= FP8_MIN_COVER, worst_cover
 
 
 def test_fp8_requires_calibration_and_taps_track_the_reference(pkg, net_golden):
